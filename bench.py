@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: replica-folds/s (MFE fill + traceback + partition function + eval_structure)
+for R=64 replicas x L=200 per GPU (BASELINE.json configs[2]) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of R sequences resident in HBM: what the reference
+does R times per Monte-Carlo iteration inside score_sequence() (utils/energy_scores.py:31-125).
+Replicas fold independently, so N GPUs each take their own R replicas (weak scaling); the only
+exchange is the all-gather of the R x N scoring-function values before a replica-exchange attempt
+(reference utils/replica_exchange_monte_carlo.py:113-173), issued every --exchange-every steps as in
+the reference's e=100 Monte-Carlo iterations per exchange step, and once after the last step.
+
+Prints ONE JSON line (rank 0).  'roofline' prices the dominant kernel's ALGORITHMIC operand bytes
+ against the 8 TB/s HBM peak; 'cpu_baseline' times the CPU oracle (a port of the
+ViennaRNA recursions; ViennaRNA itself is not on this box) on the same workload.
+"""
+import argparse
+import csv
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic operand bytes per replica-fold (MB): n -> (MFE, PF with q5-only exterior)
+B_ALG_MB = {100: (6.71, None), 200: (40.16, 80.5), 400: (221.4, None)}
+
+
+def b_alg_bytes(n):
+    """(MFE, PF) algorithmic bytes per fold; exact SURVEY figures where given, else the same formula:
+    MFE = 4(2K + I + 2E + 2C), PF(q5) = 8(2K + I + 2E + 4C) with dense term counts."""
+    C = (n - 4) * (n - 3) // 2
+    K = sum((n - d) * (d - 1) for d in range(4, n)) // 1  # all split points u of every cell
+    # the SURVEY counts splits with both parts longer than TURN: use its closed numbers when available
+    I = 0
+    for d in range(4, n):
+        cnt = 0
+        for s in range(0, 31):
+            if d - 2 - s >= 4:
+                cnt += s + 1
+        I += (n - d) * cnt
+    E = n * (n - 1) // 2
+    Ks = sum((n - d) * max(0, d - 8) for d in range(4, n))
+    mfe = 4 * (2 * Ks + I + 2 * E + 2 * C)
+    pf = 8 * (2 * Ks + I + 2 * E + 4 * C)
+    if n in B_ALG_MB:
+        m, p = B_ALG_MB[n]
+        mfe = m * 1e6
+        if p is not None:
+            pf = p * 1e6
+    return float(mfe), float(pf)
+
+
+def load_target(name):
+    with open(os.path.join(ROOT, "tests", "golden", "eterna_v1_targets.csv")) as fh:
+        for r in csv.DictReader(fh):
+            if r["name"] == name:
+                return r["structure"]
+    raise KeyError(name)
+
+
+def cpu_baseline(seqs, target, budget_s=20.0):
+    """Time the CPU oracle (kind 'port') on the GPU box's host cores; bounded sample of the same batch."""
+    from desirna_amd import params
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = pyoracle.Oracle(params.load_blob())
+    cores = os.cpu_count() or 1
+    flags = pyoracle.FLAG_PF | pyoracle.FLAG_MFE
+    # single core: 4 sequences
+    t0 = time.perf_counter()
+    orc.score_batch(seqs[:4], [target], flags, threads=1)
+    t1 = (time.perf_counter() - t0) / 4
+    # all cores: whole batch, repeated within the budget, median
+    reps = []
+    tstart = time.perf_counter()
+    while len(reps) < 5 and (time.perf_counter() - tstart) < budget_s:
+        t0 = time.perf_counter()
+        orc.score_batch(seqs, [target], flags, threads=cores)
+        reps.append(time.perf_counter() - t0)
+    tall = float(np.median(reps))
+    return {"value": len(seqs) / tall, "unit": "replica-folds/s", "cores": cores, "kind": "port",
+            "sample": "%d x L=%d sequences of the benchmark batch, %d repetitions, all %d cores (OpenMP, one fold per "
+                      "thread); single core: %.2f folds/s" % (len(seqs), len(seqs[0]), len(reps), cores, 1.0 / t1),
+            "single_core_value": 1.0 / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--replicas", type=int, default=64, help="replicas per GPU")
+    ap.add_argument("--target", default="eteV1_69.txt", help="Eterna100-V1 target giving L (69: L=200, 92: L=100, 53: L=400)")
+    ap.add_argument("--exchange-every", type=int, default=100)
+    ap.add_argument("--seqs", choices=["uniform", "design"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from desirna_amd import engine as E
+    target = load_target(args.target)
+    L, R = len(target), args.replicas
+    rng = np.random.default_rng(20260101 + rank)
+    if args.seqs == "uniform":
+        seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
+    else:
+        from desirna_amd.workloads import design_like_sequences
+        seqs = design_like_sequences(target, R, rng)
+    eng = E.Engine(max_R=R, max_L=L, device=local_rank)
+    eng.set_targets([target])
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL
+
+    d_seqs = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()).to(dev)
+    d_Epf = torch.zeros(R, dtype=torch.float64, device=dev)
+    d_Emfe = torch.zeros(R, dtype=torch.int32, device=dev)
+    d_ss = torch.zeros(R * L, dtype=torch.uint8, device=dev)
+    d_Ed = torch.zeros(R, dtype=torch.int32, device=dev)
+    gathered = torch.zeros(R * world, dtype=torch.float64, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+
+    def step(k, last):
+        eng.score_batch_device(d_seqs.data_ptr(), R, L, flags, d_Epf.data_ptr(), d_Emfe.data_ptr(),
+                               d_ss.data_ptr(), d_Ed.data_ptr())
+        if world > 1 and (last or (k + 1) % args.exchange_every == 0):
+            score = d_Ed.to(torch.float64) / 100.0 - d_Epf          # Ed - Epf, the default -sf term
+            dist.all_gather_into_tensor(gathered, score)
+
+    for k in range(args.warmup):
+        step(k, False)
+    tk = {"mfe": 0.0, "pf": 0.0, "eval": 0.0, "total": 0.0}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, k == args.steps - 1)
+        t = eng.last_timing()
+        for key in tk:
+            tk[key] += t[key]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    for key in tk:
+        tk[key] /= max(1, args.steps)
+
+    if rank == 0:
+        folds = R * world * args.steps
+        mfe_b, pf_b = b_alg_bytes(L)
+        dom = "pf" if tk["pf"] >= tk["mfe"] else "mfe"
+        dom_bytes = (pf_b if dom == "pf" else mfe_b) * R
+        dom_ms = tk[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("%s_L%d_R%d" % (dom, L, R))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "replica-folds/sec (MFE+PF, L=%d, R=%d)" % (L, R),
+            "value": folds / dt, "unit": "replica-folds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32 (MFE) + f64 (PF)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Eterna100-V1 #%s target (L=%d), R=%d %s-random sequences per GPU, "
+                                   "-sf Ed-Epf (MFE fill+traceback, PF inside, eval_structure)"
+                                   % (args.target[6:8], L, R, args.seqs),
+                       "replicas_per_gpu": R, "L": L, "exchange_every": args.exchange_every,
+                       "threads_per_workgroup": eng.info()["threads_per_wg"]},
+            "kernel_ms": {k: round(v, 4) for k, v in tk.items()},
+            "roofline": {"bound": "hbm", "kernel": "%s_kernel" % dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seqs, target)
+            out["speedup_vs_cpu_all_cores"] = out["value"] / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,312 @@
+// engine.hip -- host side of the gfx950 replica-scoring engine and its C ABI (include/desirna_amd.h).
+//
+// One engine = one GPU.  Per call the three kernel families run concurrently on their own HIP
+// streams (MFE fill+traceback, partition function, structure evaluation: they are independent per
+// sequence, reference utils/energy_scores.py:150-151,75), bracketed by HIP events so bench.py can
+// read per-kernel device times without a profiler.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/desirna_amd.h"
+#include "eval_structure.hpp"
+#include "fold_mfe.hpp"
+#include "fold_pf.hpp"
+#include "tables.hpp"
+
+using namespace drna;
+
+static std::string g_create_error;
+
+struct drna_engine {
+  int device = 0, max_R = 0, max_L = 0, nt = 1024, cus = 0;
+  HostTables H;
+  MfeTables* d_mfeT = nullptr;
+  PfTables* d_pfT = nullptr;
+  Plan* d_plan = nullptr;
+  int *d_hp_len = nullptr, *d_bulge_len = nullptr, *d_int_len = nullptr;
+  double *d_hp_w = nullptr, *d_scale = nullptr, *d_eMLb = nullptr;
+  int32_t* d_ws_mfe = nullptr;
+  double* d_ws_pf = nullptr;
+  size_t ws_bytes = 0;
+  // staging for the host-buffer entry point
+  char* d_seqs = nullptr;
+  double* d_Epf = nullptr;
+  int32_t* d_Emfe = nullptr;
+  char* d_ss = nullptr;
+  int32_t* d_Ed = nullptr;
+  size_t ed_cap = 0;
+  // per-sequence status words, host-mapped so no copy is needed after the streams drain
+  int32_t *h_status = nullptr, *d_status = nullptr;   // [0,R) mfe, [max_R, max_R+R) pf
+  short* d_pt = nullptr;
+  int n_targets = 0, L_targets = 0;
+  hipStream_t s_mfe = nullptr, s_pf = nullptr, s_eval = nullptr;
+  hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_m0 = nullptr, ev_m1 = nullptr, ev_p0 = nullptr,
+             ev_p1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
+  float timing[4] = {0, 0, 0, 0};
+  std::string err;
+};
+
+#define HIP_TRY(call)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (call);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      e->err = std::string(#call) + ": " + hipGetErrorString(_e);                          \
+      return DRNA_ERR_DEVICE;                                                              \
+    }                                                                                      \
+  } while (0)
+
+template <typename T>
+static hipError_t upload(T** dst, const T* src, size_t count) {
+  hipError_t r = hipMalloc((void**)dst, count * sizeof(T));
+  if (r != hipSuccess) return r;
+  return hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+static size_t mfe_ws_stride(int ld) { return (size_t)5 * ld * ld; }                       // int32
+static size_t pf_ws_stride(int ld) { return (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8; }  // doubles
+
+static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int device, int max_R, int max_L) {
+  if (!params || max_R < 1 || max_L < 1 || max_L > MAXN - 2) {
+    e->err = "drna_create: bad argument (1 <= max_L <= 2046, max_R >= 1)";
+    return DRNA_ERR_ARG;
+  }
+  std::string msg = build_tables(params, n_int32, e->H);
+  if (!msg.empty()) { e->err = msg; return DRNA_ERR_PARAMS; }
+  size_tables(e->H, max_L + 2);
+  e->device = device; e->max_R = max_R; e->max_L = max_L;
+  if (const char* s = getenv("DRNA_NT")) {
+    int v = atoi(s);
+    if (v == 256 || v == 512 || v == 1024) e->nt = v;
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  e->cus = prop.multiProcessorCount;
+  HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
+  HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
+  HIP_TRY(upload(&e->d_plan, &e->H.plan, 1));
+  HIP_TRY(upload(&e->d_hp_len, e->H.hp_len.data(), e->H.hp_len.size()));
+  HIP_TRY(upload(&e->d_bulge_len, e->H.bulge_len.data(), e->H.bulge_len.size()));
+  HIP_TRY(upload(&e->d_int_len, e->H.int_len.data(), e->H.int_len.size()));
+  HIP_TRY(upload(&e->d_hp_w, e->H.hp_w.data(), e->H.hp_w.size()));
+  HIP_TRY(upload(&e->d_scale, e->H.scale.data(), e->H.scale.size()));
+  HIP_TRY(upload(&e->d_eMLb, e->H.eMLb.data(), e->H.eMLb.size()));
+  const int ld = max_L + 2;
+  size_t bm = mfe_ws_stride(ld) * sizeof(int32_t) * max_R, bp = pf_ws_stride(ld) * sizeof(double) * max_R;
+  HIP_TRY(hipMalloc((void**)&e->d_ws_mfe, bm));
+  HIP_TRY(hipMalloc((void**)&e->d_ws_pf, bp));
+  e->ws_bytes = bm + bp;
+  HIP_TRY(hipMalloc((void**)&e->d_seqs, (size_t)max_R * max_L));
+  HIP_TRY(hipMalloc((void**)&e->d_Epf, (size_t)max_R * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&e->d_Emfe, (size_t)max_R * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&e->d_ss, (size_t)max_R * max_L));
+  HIP_TRY(hipHostMalloc((void**)&e->h_status, (size_t)2 * max_R * sizeof(int32_t), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->d_status, e->h_status, 0));
+  memset(e->h_status, 0, (size_t)2 * max_R * sizeof(int32_t));
+  HIP_TRY(hipStreamCreateWithFlags(&e->s_mfe, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&e->s_pf, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&e->s_eval, hipStreamNonBlocking));
+  hipEvent_t* evs[] = {&e->ev_start, &e->ev_end, &e->ev_m0, &e->ev_m1, &e->ev_p0, &e->ev_p1, &e->ev_e0, &e->ev_e1};
+  for (hipEvent_t* ev : evs) HIP_TRY(hipEventCreate(ev));
+  return DRNA_OK;
+}
+
+extern "C" int drna_create(const int32_t* params, int n_int32, int device, int max_R, int max_L, drna_engine** out) {
+  if (!out) return DRNA_ERR_ARG;
+  *out = nullptr;
+  drna_engine* e = new drna_engine();
+  int rc = create_impl(e, params, n_int32, device, max_R, max_L);
+  if (rc != DRNA_OK) {
+    g_create_error = e->err;
+    drna_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return DRNA_OK;
+}
+
+extern "C" void drna_destroy(drna_engine* e) {
+  if (!e) return;
+  void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
+                  e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (e->h_status) (void)hipHostFree(e->h_status);
+  hipStream_t ss[] = {e->s_mfe, e->s_pf, e->s_eval};
+  for (hipStream_t s : ss)
+    if (s) (void)hipStreamDestroy(s);
+  hipEvent_t evs[] = {e->ev_start, e->ev_end, e->ev_m0, e->ev_m1, e->ev_p0, e->ev_p1, e->ev_e0, e->ev_e1};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  delete e;
+}
+
+extern "C" const char* drna_last_error(const drna_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int drna_set_targets(drna_engine* e, int n_targets, int L, const char* targets) {
+  if (!e) return DRNA_ERR_ARG;
+  if (n_targets < 0 || L < 1 || L > e->max_L || (n_targets > 0 && !targets)) {
+    e->err = "drna_set_targets: bad argument";
+    return DRNA_ERR_ARG;
+  }
+  std::vector<short> pt((size_t)n_targets * (L + 2), 0);
+  std::vector<int> stk;
+  for (int k = 0; k < n_targets; k++) {
+    stk.clear();
+    const char* s = targets + (size_t)k * L;
+    short* p = pt.data() + (size_t)k * (L + 2);
+    for (int i = 1; i <= L; i++) {
+      if (s[i - 1] == '(') stk.push_back(i);
+      else if (s[i - 1] == ')') {
+        if (stk.empty()) { e->err = "drna_set_targets: unbalanced ')'"; return DRNA_ERR_STRUCTURE; }
+        int o = stk.back(); stk.pop_back();
+        p[o] = (short)i; p[i] = (short)o;
+      }
+    }
+    if (!stk.empty()) { e->err = "drna_set_targets: unbalanced '('"; return DRNA_ERR_STRUCTURE; }
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->d_pt) { (void)hipFree(e->d_pt); e->d_pt = nullptr; }
+  if (e->d_Ed) { (void)hipFree(e->d_Ed); e->d_Ed = nullptr; }
+  e->n_targets = n_targets; e->L_targets = L;
+  if (n_targets) {
+    HIP_TRY(upload(&e->d_pt, pt.data(), pt.size()));
+    HIP_TRY(hipMalloc((void**)&e->d_Ed, (size_t)e->max_R * n_targets * sizeof(int32_t)));
+  }
+  return DRNA_OK;
+}
+
+template <int NT>
+static void launch_mfe(const MfeArgs& a, int R, hipStream_t s) {
+  hipLaunchKernelGGL(mfe_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+template <int NT>
+static void launch_pf(const PfArgs& a, int R, hipStream_t s) {
+  hipLaunchKernelGGL(pf_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+
+extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char* d_seqs, uint32_t flags, double* d_Epf,
+                                       int32_t* d_Emfe, char* d_mfe_ss, int32_t* d_Ed) {
+  if (!e) return DRNA_ERR_ARG;
+  const bool want_pf = flags & DRNA_NEED_PF, want_mfe = flags & (DRNA_NEED_MFE | DRNA_NEED_PK),
+             want_pk = flags & DRNA_NEED_PK, want_ev = flags & DRNA_NEED_EVAL;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || !d_seqs || (want_pf && !d_Epf) ||
+      (want_mfe && (!d_Emfe || !d_mfe_ss)) || (want_ev && !d_Ed)) {
+    e->err = "drna_score_batch: bad argument (R, L within the engine's limits; output pointers for every requested flag)";
+    return DRNA_ERR_ARG;
+  }
+  if (want_ev && (e->n_targets < 1 || e->L_targets != L)) {
+    e->err = "drna_score_batch: DRNA_NEED_EVAL needs drna_set_targets() with the same L";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const int ld = L + 2;
+  for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
+  HIP_TRY(hipEventRecord(e->ev_start, e->s_mfe));
+  HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_start, 0));
+  HIP_TRY(hipStreamWaitEvent(e->s_eval, e->ev_start, 0));
+  if (want_mfe) {
+    MfeArgs a;
+    a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = d_seqs; a.L = L; a.ld = ld;
+    a.pk_rounds = want_pk ? 3 : 0;
+    a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
+    a.Emfe = d_Emfe; a.ss = d_mfe_ss; a.status = e->d_status;
+    HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+    if (e->nt == 256) launch_mfe<256>(a, R, e->s_mfe);
+    else if (e->nt == 512) launch_mfe<512>(a, R, e->s_mfe);
+    else launch_mfe<1024>(a, R, e->s_mfe);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+  }
+  if (want_pf) {
+    PfArgs a;
+    a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
+    a.seqs = d_seqs; a.L = L; a.ld = ld;
+    a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
+    a.Epf = d_Epf; a.status = e->d_status + e->max_R;
+    HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
+    if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
+    else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
+    else launch_pf<1024>(a, R, e->s_pf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
+    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_p1, 0));
+  }
+  if (want_ev) {
+    EvalArgs a;
+    a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
+    a.seqs = d_seqs; a.pt = e->d_pt; a.L = L; a.n_targets = e->n_targets; a.Ed = d_Ed;
+    HIP_TRY(hipEventRecord(e->ev_e0, e->s_eval));
+    hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, e->s_eval, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_e1, e->s_eval));
+    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_e1, 0));
+  }
+  HIP_TRY(hipEventRecord(e->ev_end, e->s_mfe));
+  HIP_TRY(hipStreamSynchronize(e->s_mfe));
+  e->timing[0] = e->timing[1] = e->timing[2] = 0.f;
+  if (want_mfe) HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
+  if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
+  if (want_ev) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
+  HIP_TRY(hipEventElapsedTime(&e->timing[3], e->ev_start, e->ev_end));
+  for (int r = 0; r < R; r++) {
+    const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
+    const int st = sm != ST_OK ? sm : sp;
+    if (st == ST_OK) continue;
+    char buf[160];
+    if (st == ST_BAD_CHAR) {
+      snprintf(buf, sizeof buf, "sequence %d holds a character other than A C G U T", r);
+      e->err = buf;
+      return DRNA_ERR_SEQUENCE;
+    }
+    if (st == ST_PF_RANGE) {
+      snprintf(buf, sizeof buf, "sequence %d: partition function left the fp64 range (pf_scale too small/large)", r);
+      e->err = buf;
+      return DRNA_ERR_PF_RANGE;
+    }
+    snprintf(buf, sizeof buf, "sequence %d: traceback could not reproduce a table value", r);
+    e->err = buf;
+    return DRNA_ERR_INTERNAL;
+  }
+  return DRNA_OK;
+}
+
+extern "C" int drna_score_batch(drna_engine* e, int R, int L, const char* seqs, uint32_t flags, double* Epf,
+                                int32_t* Emfe, char* mfe_ss, int32_t* Ed) {
+  if (!e) return DRNA_ERR_ARG;
+  const bool want_pf = flags & DRNA_NEED_PF, want_mfe = flags & (DRNA_NEED_MFE | DRNA_NEED_PK),
+             want_ev = flags & DRNA_NEED_EVAL;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || !seqs || (want_pf && !Epf) || (want_mfe && (!Emfe || !mfe_ss)) ||
+      (want_ev && !Ed)) {
+    e->err = "drna_score_batch: bad argument (R, L within the engine's limits; output pointers for every requested flag)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
+  int rc = drna_score_batch_device(e, R, L, e->d_seqs, flags, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed);
+  if (rc != DRNA_OK) return rc;
+  if (want_pf) HIP_TRY(hipMemcpy(Epf, e->d_Epf, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
+  if (want_mfe) {
+    HIP_TRY(hipMemcpy(Emfe, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, (size_t)R * L, hipMemcpyDeviceToHost));
+  }
+  if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * e->n_targets * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
+
+extern "C" int drna_last_timing(const drna_engine* e, float out[4]) {
+  if (!e || !out) return DRNA_ERR_ARG;
+  for (int k = 0; k < 4; k++) out[k] = e->timing[k];
+  return DRNA_OK;
+}
+
+extern "C" int drna_info(const drna_engine* e, int64_t out[6]) {
+  if (!e || !out) return DRNA_ERR_ARG;
+  out[0] = e->device; out[1] = e->max_R; out[2] = e->max_L; out[3] = e->nt; out[4] = e->cus; out[5] = (int64_t)e->ws_bytes;
+  return DRNA_OK;
+}

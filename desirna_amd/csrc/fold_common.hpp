@@ -1,0 +1,72 @@
+// fold_common.hpp -- device helpers shared by the gfx950 fold kernels (wave64).
+#pragma once
+#include <stdint.h>
+
+#include "tables.hpp"
+
+namespace drna {
+
+constexpr int WAVE = 64;
+constexpr int MAXN = 2048;        // static LDS sizing of the per-sequence arrays
+constexpr int PART_ITEMS = 32;    // (cell-block, chunk) work items per diagonal held in LDS
+
+// kernel status codes (per sequence)
+enum : int { ST_OK = 0, ST_BAD_CHAR = 1, ST_TRACEBACK = 2, ST_PF_RANGE = 3 };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int w = __shfl_xor(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// fixed-order butterfly sum: every lane ends with the same bits
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// lowest set lane of a ballot, or -1
+__device__ __forceinline__ int first_lane(unsigned long long m) { return m ? (__ffsll((long long)m) - 1) : -1; }
+
+__device__ __forceinline__ int enc_nt(char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'U': case 'u': case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+// pair type from two pairing codes (0..3 = A C G U, 4 = must stay unpaired)
+__device__ __forceinline__ int pair_type(int a, int b) {
+  // CG=1 GC=2 GU=3 UG=4 AU=5 UA=6
+  if (a > 3 || b > 3) return 0;
+  const int s = a * 4 + b;
+  // packed 4-bit LUT: index s -> type
+  // (A,U)=3 ->5 ; (C,G)=6 ->1 ; (G,C)=9 ->2 ; (G,U)=11 ->3 ; (U,A)=12 ->6 ; (U,G)=14 ->4
+  const unsigned long long lut = (5ull << (3 * 4)) | (1ull << (6 * 4)) | (2ull << (9 * 4)) | (3ull << (11 * 4)) |
+                                 (6ull << (12 * 4)) | (4ull << (14 * 4));
+  return (int)((lut >> (s * 4)) & 15ull);
+}
+
+__device__ __forceinline__ int rtype_of(int t) {
+  // {0,2,1,4,3,6,5,7}
+  const unsigned lut = 0x75634120u;
+  return (int)((lut >> (t * 4)) & 15u);
+}
+
+}  // namespace drna

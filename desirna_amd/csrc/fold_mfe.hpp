@@ -1,0 +1,485 @@
+// fold_mfe.hpp -- Zuker MFE fill + traceback (+ greedy pseudoknot re-folds) for one sequence per
+// workgroup on gfx950.  Replaces, for a whole batch of replicas at once:
+//   fc.mfe()                     reference utils/energy_scores.py:151   
+//   RNA.fold(seq)[1]             reference utils/energy_scores.py:354   (f5[n] of the same fill)
+//   get_pk_struct(seq, ss, fc)   reference utils/sequence_utils.py:1166-1228
+// Recursions and traceback order: SURVEY.md App. A.3/A.4 (ViennaRNA 2.6.4 model, dangles=2).
+//
+// Design (MI355X): one workgroup per sequence sweeps the anti-diagonals d = j-i.  Tables live in
+// HBM/L2 in DIAGONAL-MAJOR layout (row d holds cells (i, i+d), i = 1..n-d) so that, with one LANE per
+// cell, every operand stream of both inner loops is unit-stride across the wave:
+//   interior loop  (p,q) = (i+1+u1, j-1-u2)  ->  row d-2-u1-u2, column i+1+u1   (u1,u2 wave-uniform)
+//   multiloop split fML[i,u] + fML[u+1,j]     ->  row tt, column i   and   row d-tt-1, column i+tt+1
+// Loop-size terms are wave-uniform scalars taken from a host-built plan (tables.hpp), the work of a
+// diagonal is cut into (64-cell block) x (chunk of the candidate/split lists) items spread over the
+// waves, partial minima meet in LDS, and one lane per cell finalises c / fML.
+// Per cell two words are stored: Wc = (c << 8) | info  and  CI = c + mismatchI[info], so the dominant
+// "generic" interior candidates cost one load + add + min.
+#pragma once
+#include "fold_common.hpp"
+
+namespace drna {
+
+struct MfeArgs {
+  const MfeTables* T;
+  const Plan* plan;
+  const int* hp_len;           // hairpin energy by loop size, >= L+2 entries
+  const char* seqs;            // R x L ASCII
+  int L;
+  int ld;                      // row pitch of the per-sequence tables (>= L+2)
+  int pk_rounds;               // 0 = plain MFE, 3 = reference pseudoknot heuristic
+  int32_t* ws;                 // workspace: per sequence 5 tables of ld*ld int32
+  long long ws_stride;         // int32 per sequence
+  int32_t* Emfe;               // R  (dcal/mol, ViennaRNA INF convention not needed: always finite)
+  char* ss;                    // R x L structure (pk-annotated if pk_rounds)
+  int32_t* status;             // R
+};
+
+struct MfeSmem {
+  int stack[64];
+  int mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128];
+  int int11[1024];
+  int d5[32], d3[32];
+  int partI[PART_ITEMS * WAVE];
+  int partK[PART_ITEMS * WAVE];
+  int f5[MAXN + 2];
+  short sec_i[MAXN + 2], sec_j[MAXN + 2];
+  unsigned char sec_ml[MAXN + 2];
+  unsigned char S[MAXN + 4];    // nucleotide codes, S[0] = S[n], S[n+1] = S[1]
+  unsigned char Sp[MAXN + 4];   // pairing codes (4 = hard-constrained unpaired)
+  char ssw[MAXN + 4];           // structure of the current round
+  char sspk[MAXN + 4];          // accumulated (pk-annotated) structure
+  int flag;
+};
+
+// ---- loop energies on the device (per-lane arguments; used by finalize and traceback)
+
+__device__ __forceinline__ int mfe_hairpin(const MfeSmem& sm, const MfeArgs& A, int i, int j, int t) {
+  const MfeTables& T = *A.T;
+  const int u = j - i - 1;
+  const int e = A.hp_len[u];
+  const int tau = t > 2 ? T.TermAU : 0;
+  if (u == 3) {
+    if (T.n_tri) {
+      int code = 0;
+      for (int k = 0; k < 5; k++) code |= sm.S[i + k] << (2 * k);
+      for (int k = 0; k < T.n_tri; k++)
+        if (T.tri_code[k] == code) return T.tri_e[k];
+    }
+    return e + tau;
+  }
+  if (u == 4 && T.n_tetra) {
+    int code = 0;
+    for (int k = 0; k < 6; k++) code |= sm.S[i + k] << (2 * k);
+    for (int k = 0; k < T.n_tetra; k++)
+      if (T.tetra_code[k] == code) return T.tetra_e[k];
+  } else if (u == 6 && T.n_hexa) {
+    int code = 0;
+    for (int k = 0; k < 8; k++) code |= sm.S[i + k] << (2 * k);
+    for (int k = 0; k < T.n_hexa; k++)
+      if (T.hexa_code[k] == code) return T.hexa_e[k];
+  }
+  return e + sm.mmH[t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1]];
+}
+
+// ViennaRNA E_IntLoop with the inner pair given by its packed info byte; arbitrary per-lane (u1,u2)
+__device__ __forceinline__ int mfe_intloop(const MfeSmem& sm, const MfeTables& T, int u1, int u2, int t,
+                                           int si1, int sj1, int info) {
+  const int t2 = info >> 4, sq1 = (info >> 2) & 3, sp1 = info & 3;
+  const int nl = u1 > u2 ? u1 : u2, ns = u1 > u2 ? u2 : u1;
+  if (nl == 0) return sm.stack[t * 8 + t2];
+  if (ns == 0) {
+    int e = T.bulge[nl];
+    if (nl == 1) return e + sm.stack[t * 8 + t2];
+    return e + (t > 2 ? T.TermAU : 0) + (t2 > 2 ? T.TermAU : 0);
+  }
+  if (ns == 1) {
+    if (nl == 1) return sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1];
+    if (nl == 2)
+      return (u1 == 1) ? T.int21[(t * 8 + t2) * 64 + si1 * 16 + sq1 * 4 + sj1]
+                       : T.int21[(t2 * 8 + t) * 64 + sq1 * 16 + si1 * 4 + sp1];
+    int e = T.interior[nl + 1] + min(T.max_ninio, (nl - ns) * T.ninio);
+    return e + sm.mm1n[t * 16 + si1 * 4 + sj1] + sm.mm1n[info];
+  }
+  if (ns == 2) {
+    if (nl == 2) return T.int22[(t * 8 + t2) * 256 + si1 * 64 + sp1 * 16 + sq1 * 4 + sj1];
+    if (nl == 3) return T.interior[5] + T.ninio + sm.mm23[t * 16 + si1 * 4 + sj1] + sm.mm23[info];
+  }
+  int e = T.interior[nl + ns] + min(T.max_ninio, (nl - ns) * T.ninio);
+  return e + sm.mmI[t * 16 + si1 * 4 + sj1] + sm.mmI[info];
+}
+
+__device__ __forceinline__ int mfe_extstem(const MfeSmem& sm, int t, int i, int j, int n) {
+  // E_ExtLoop(type, i>1 ? S[i-1] : -1, j<n ? S[j+1] : -1), dangles = 2
+  int e;
+  if (i > 1 && j < n) e = sm.mmExt[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]];
+  else if (i > 1) e = sm.d5[t * 4 + sm.S[i - 1]];
+  else if (j < n) e = sm.d3[t * 4 + sm.S[j + 1]];
+  else e = 0;
+  return e;
+}
+
+// ---- fill of one sequence (all threads of the workgroup)
+
+template <int NT>
+__device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ CI,
+                         int32_t* __restrict__ FML, int32_t* __restrict__ DML, int32_t* __restrict__ EXT) {
+  constexpr int NW = NT / WAVE;
+  const MfeTables& T = *A.T;
+  const Plan& P = *A.plan;
+  const int n = A.L, ld = A.ld;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());   // SGPR: items, plan entries and branches stay scalar
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int segG = P.seg[PK_GENERIC];
+
+  // rows read before they are written: fML diag 3, decomp diags 2 and 3
+  for (int k = tid; k < ld; k += NT) {
+    FML[3 * ld + k] = INF;
+    DML[2 * ld + k] = INF;
+    DML[3 * ld + k] = INF;
+  }
+  __syncthreads();
+
+  for (int d = TURN + 1; d < n; d++) {
+    const int ncell = n - d;
+    const int nblk = (ncell + WAVE - 1) / WAVE;
+    int H = NW / nblk;
+    if (H < 1) H = 1;
+    const int nitems = nblk * H;
+
+    // ---------------- phase A: candidate minima, lane = cell
+    for (int item = wave; item < nitems; item += NW) {
+      const int b = item / H, h = item - b * H;
+      const int i0 = b * WAVE + lane + 1;
+      const bool act = i0 <= ncell;
+      const int i = act ? i0 : ncell;
+      const int j = i + d;
+      const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+      const int ij = t * 16 + si1 * 4 + sj1;
+      int accI = INF;
+      if (__ballot(act && t != 0) != 0ull) {
+        const int tau = t > 2 ? T.TermAU : 0;
+        // special kinds (stack, bulges, 1x1, 2x1, 1xn, 2x2, 2x3): strided over the chunk
+        for (int e = h; e < segG; e += H) {
+          const int u1 = P.u1[e], u2 = P.u2[e];
+          const int dp = d - 2 - u1 - u2;
+          if (dp <= TURN) continue;
+          const int w = Wc[dp * ld + i + 1 + u1];
+          const int cpq = w >> 8, info = w & 127, t2 = info >> 4;
+          int en;
+          switch (P.kind[e]) {
+            case PK_STACK: en = cpq + sm.stack[t * 8 + t2]; break;
+            case PK_BULGE1: en = cpq + P.L[e] + sm.stack[t * 8 + t2]; break;
+            case PK_BULGEN: en = cpq + P.L[e] + tau + (t2 > 2 ? T.TermAU : 0); break;
+            case PK_INT11: en = cpq + sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+            case PK_INT21: en = cpq + T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
+            case PK_INT12: en = cpq + T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
+            case PK_1XN: en = cpq + P.L[e] + sm.mm1n[ij] + sm.mm1n[info]; break;
+            case PK_INT22:
+              en = cpq + T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
+              break;
+            default: /* PK_INT23 */ en = cpq + P.L[e] + sm.mm23[ij] + sm.mm23[info]; break;
+          }
+          accI = min(accI, en);
+        }
+        // generic interior loops: c + mismatchI(inner) precombined in CI, size term is a scalar
+        int accG = INF;
+        for (int e = segG + h; e < NPLAN; e += H) {
+          const int u1 = P.u1[e];
+          const int dp = d - 2 - u1 - P.u2[e];
+          if (dp <= TURN) continue;
+          accG = min(accG, CI[dp * ld + i + 1 + u1] + P.L[e]);
+        }
+        accI = min(accI, accG + sm.mmI[ij]);
+      }
+      // multiloop split: fML[i,u] + fML[u+1,j], u = i + tt
+      int accK = INF;
+      for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
+        accK = min(accK, FML[tt * ld + i] + FML[(d - tt - 1) * ld + i + tt + 1]);
+      sm.partI[item * WAVE + lane] = accI;
+      sm.partK[item * WAVE + lane] = accK;
+    }
+    __syncthreads();
+
+    // ---------------- phase B: one lane per cell finalises c and fML
+    for (int i = tid + 1; i <= ncell; i += NT) {
+      const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
+      int aI = INF, aK = INF;
+      for (int h = 0; h < H; h++) {
+        aI = min(aI, sm.partI[(b * H + h) * WAVE + ln]);
+        aK = min(aK, sm.partK[(b * H + h) * WAVE + ln]);
+      }
+      const int j = i + d;
+      const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      const int tau = t > 2 ? T.TermAU : 0;
+      int c = INF;
+      int info = 0;
+      if (t) {
+        c = mfe_hairpin(sm, A, i, j, t);
+        c = min(c, aI);
+        const int dml = DML[(d - 2) * ld + i + 1];
+        if (dml < HALF)
+          c = min(c, dml + T.MLclosing + T.MLintern + tau + sm.mmM[rtype_of(t) * 16 + sm.S[j - 1] * 4 + sm.S[i + 1]]);
+        if (c >= HALF) c = INF;
+        info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
+      }
+      Wc[d * ld + i] = c * 256 + info;
+      CI[d * ld + i] = c < INF ? c + sm.mmI[info] : INF;
+      EXT[j * ld + i] = c < INF ? c + tau + mfe_extstem(sm, t, i, j, n) : INF;
+      int f = INF;
+      const int fa = FML[(d - 1) * ld + i + 1], fb = FML[(d - 1) * ld + i];
+      if (fa < HALF) f = fa + T.MLbase;
+      if (fb < HALF) f = min(f, fb + T.MLbase);
+      if (c < INF) f = min(f, c + T.MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
+      const int dec = aK >= HALF ? INF : aK;
+      DML[d * ld + i] = dec;
+      FML[d * ld + i] = min(f, dec);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- exterior loop f5 (wave 0; column j of EXT is unit-stride)
+  if (wave == 0) {
+    for (int j = lane; j <= TURN + 1 && j <= n; j += WAVE) sm.f5[j] = 0;
+    for (int j = TURN + 2; j <= n; j++) {
+      int m = INF;
+      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
+        const int x = EXT[j * ld + i];
+        if (x < HALF) m = min(m, sm.f5[i - 1] + x);
+      }
+      m = wave_min_i32(m);
+      const int prev = sm.f5[j - 1];
+      sm.f5[j] = prev < m ? prev : m;   // every lane stores the same value
+    }
+  }
+  __syncthreads();
+}
+
+// ---- traceback by wave 0 (wave-uniform control flow, lanes scan candidates in ViennaRNA's order)
+
+__device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
+                                     const int32_t* __restrict__ FML, const int32_t* __restrict__ EXT) {
+  const MfeTables& T = *A.T;
+  const Plan& P = *A.plan;
+  const int n = A.L, ld = A.ld, lane = lane_id();
+  const int HALF = INF_DEV / 2;
+  int sp = 0;
+  bool ok = true;
+  // sector stack lives in LDS; every lane keeps the same sp
+  sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 0; sp = 1;
+  while (sp > 0 && ok) {
+    sp--;
+    int i = sm.sec_i[sp], j = sm.sec_j[sp];
+    const int ml = sm.sec_ml[sp];
+    bool have_pair = false;
+    if (ml == 0) {
+      // ---- exterior: vrna_BT_ext_loop_f5
+      if (j < TURN + 2) continue;
+      // largest jj <= j with f5[jj] != f5[jj-1]
+      int jj = -1;
+      for (int base = j; base >= 1 && jj < 0; base -= WAVE) {
+        const int x = base - lane;
+        const bool hit = x >= 1 && sm.f5[x] != sm.f5[x - 1];
+        const int fl = first_lane(__ballot(hit));
+        if (fl >= 0) jj = base - fl;
+      }
+      if (jj < TURN + 2) continue;
+      const int fij = sm.f5[jj];
+      int u = -1;
+      for (int base = jj - TURN - 1; base >= 1 && u < 0; base -= WAVE) {
+        const int x = base - lane;
+        bool hit = false;
+        if (x >= 1) {
+          const int e = EXT[jj * ld + x];
+          hit = e < HALF && fij == e + sm.f5[x - 1];
+        }
+        const int fl = first_lane(__ballot(hit));
+        if (fl >= 0) u = base - fl;
+      }
+      if (u < 0) { ok = false; break; }
+      sm.sec_i[sp] = 1; sm.sec_j[sp] = (short)(u - 1); sm.sec_ml[sp] = 0; sp++;
+      i = u; j = jj; have_pair = true;
+    } else if (ml == 1) {
+      // ---- multiloop segment: vrna_BT_mb_loop_split
+      // strip unpaired 3' bases: largest run k with fML[i,j-k] == fML[i,j-k-1] + MLbase
+      for (;;) {
+        const int jx = j - lane;            // lane tests position jx
+        bool stop = true;
+        if (jx > i) {
+          const int a = FML[(jx - i) * ld + i], bq = (jx - 1 - i) >= 0 ? FML[(jx - 1 - i) * ld + i] : INF_DEV;
+          stop = !(a == bq + T.MLbase);
+        }
+        const int fl = first_lane(__ballot(stop));
+        if (fl >= 0) { j -= fl; break; }
+        j -= WAVE;
+      }
+      for (;;) {
+        const int ix = i + lane;
+        bool stop = true;
+        if (ix < j) {
+          const int a = FML[(j - ix) * ld + ix], bq = FML[(j - ix - 1) * ld + ix + 1];
+          stop = !(a == bq + T.MLbase);
+        }
+        const int fl = first_lane(__ballot(stop));
+        if (fl >= 0) { i += fl; break; }
+        i += WAVE;
+      }
+      if (j < i + TURN + 1) { ok = false; break; }
+      const int d = j - i;
+      const int fij = FML[d * ld + i];
+      const int w = Wc[d * ld + i];
+      const int cij = w >> 8;
+      const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      if (t && cij < HALF &&
+          fij == cij + T.MLintern + (t > 2 ? T.TermAU : 0) + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]) {
+        have_pair = true;
+      } else {
+        int u = -1;
+        for (int base = i + TURN + 1; base <= j - TURN - 2 && u < 0; base += WAVE) {
+          const int x = base + lane;
+          bool hit = false;
+          if (x <= j - TURN - 2) hit = fij == FML[(x - i) * ld + i] + FML[(j - x - 1) * ld + x + 1];
+          const int fl = first_lane(__ballot(hit));
+          if (fl >= 0) u = base + fl;
+        }
+        if (u < 0) { ok = false; break; }
+        sm.sec_i[sp] = (short)i; sm.sec_j[sp] = (short)u; sm.sec_ml[sp] = 1; sp++;
+        sm.sec_i[sp] = (short)(u + 1); sm.sec_j[sp] = (short)j; sm.sec_ml[sp] = 1; sp++;
+      }
+    } else {
+      have_pair = true;
+    }
+    // ---- pair (i,j): hairpin, interior (p ascending, q descending), multiloop
+    while (have_pair) {
+      if (lane == 0) { sm.ssw[i - 1] = '('; sm.ssw[j - 1] = ')'; }
+      const int d = j - i;
+      const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      const int cij = Wc[d * ld + i] >> 8;
+      if (cij == mfe_hairpin(sm, A, i, j, t)) break;
+      const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+      int found = -1;
+      for (int base = 0; base < NPLAN && found < 0; base += WAVE) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < NPLAN) {
+          const int u1 = P.tb_u1[k], u2 = P.tb_u2[k];
+          const int dp = d - 2 - u1 - u2;
+          if (dp > TURN) {
+            const int w = Wc[dp * ld + i + 1 + u1];
+            const int cpq = w >> 8;
+            if (cpq < HALF) hit = cij == cpq + mfe_intloop(sm, T, u1, u2, t, si1, sj1, w & 127);
+          }
+        }
+        const int fl = first_lane(__ballot(hit));
+        if (fl >= 0) found = base + fl;
+      }
+      if (found >= 0) {
+        i = i + 1 + P.tb_u1[found];
+        j = j - 1 - P.tb_u2[found];
+        continue;
+      }
+      // multiloop closed by (i,j): vrna_BT_mb_loop
+      const int e = cij - T.MLclosing - T.MLintern - (t > 2 ? T.TermAU : 0) -
+                    sm.mmM[rtype_of(t) * 16 + sj1 * 4 + si1];
+      int u = -1;
+      for (int base = i + 2 + TURN; base < j - 2 - TURN && u < 0; base += WAVE) {
+        const int x = base + lane;
+        bool hit = false;
+        if (x < j - 2 - TURN) hit = e == FML[(x - i - 1) * ld + i + 1] + FML[(j - 1 - x - 1) * ld + x + 1];
+        const int fl = first_lane(__ballot(hit));
+        if (fl >= 0) u = base + fl;
+      }
+      if (u < 0) { ok = false; break; }
+      sm.sec_i[sp] = (short)(i + 1); sm.sec_j[sp] = (short)u; sm.sec_ml[sp] = 1; sp++;
+      sm.sec_i[sp] = (short)(u + 1); sm.sec_j[sp] = (short)(j - 1); sm.sec_ml[sp] = 1; sp++;
+      break;
+    }
+  }
+  return ok;
+}
+
+// ---- the kernel: one workgroup per sequence
+
+template <int NT>
+__global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
+  __shared__ MfeSmem sm;
+  const int r = blockIdx.x;
+  const int n = A.L, ld = A.ld, tid = threadIdx.x;
+  const MfeTables& T = *A.T;
+  int32_t* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  int32_t* Wc = base;
+  int32_t* CI = base + tab;
+  int32_t* FML = base + 2 * tab;
+  int32_t* DML = base + 3 * tab;
+  int32_t* EXT = base + 4 * tab;
+
+  for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
+  for (int k = tid; k < 128; k += NT) {
+    sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
+    sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
+  }
+  for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
+  for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  if (tid == 0) sm.flag = 0;
+  __syncthreads();
+  const char* seq = A.seqs + (long long)r * n;
+  for (int k = tid; k < n; k += NT) {
+    const int c = enc_nt(seq[k]);
+    if (c < 0) sm.flag = 1;
+    sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
+    sm.Sp[k + 1] = (unsigned char)(c < 0 ? 4 : c);
+    sm.sspk[k] = '.';
+  }
+  __syncthreads();
+  if (tid == 0) {
+    sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1];
+    sm.Sp[0] = 4; sm.Sp[n + 1] = 4;
+  }
+  __syncthreads();
+  if (sm.flag) {
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; }
+    for (int k = tid; k < n; k += NT) A.ss[(long long)r * n + k] = '.';
+    return;
+  }
+
+  int status = ST_OK;
+  for (int round = 0; round <= A.pk_rounds; round++) {
+    for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
+    mfe_fill<NT>(sm, A, Wc, CI, FML, DML, EXT);     // ends with a barrier
+    if (wave_id() == 0) {
+      const bool ok = mfe_traceback(sm, A, Wc, FML, EXT);
+      if (lane_id() == 0) {
+        if (round == 0) A.Emfe[r] = sm.f5[n];
+        sm.flag = ok ? 0 : 1;
+      }
+    }
+    __syncthreads();
+    if (sm.flag) { status = ST_TRACEBACK; break; }
+    // merge this round into the annotated structure; bracket family of round k: () [] <> {}
+    const char op = round == 0 ? '(' : round == 1 ? '[' : round == 2 ? '<' : '{';
+    const char cl = round == 0 ? ')' : round == 1 ? ']' : round == 2 ? '>' : '}';
+    __syncthreads();
+    int any = 0;
+    for (int k = tid; k < n; k += NT) {
+      const char ch = sm.ssw[k];
+      if (ch == '(') { sm.sspk[k] = op; any = 1; }
+      else if (ch == ')') sm.sspk[k] = cl;
+      if (sm.sspk[k] != '.') sm.Sp[k + 1] = 4;      // hc 'x': already paired positions stay unpaired
+    }
+    if (any) sm.flag = 2;
+    __syncthreads();
+    // reference sequence_utils.py:1194,1210: the next re-fold happens only if this one found a pair
+    const bool more = (round == 0) || (sm.flag == 2);
+    __syncthreads();
+    if (tid == 0) sm.flag = 0;
+    __syncthreads();
+    if (!more) break;
+  }
+  for (int k = tid; k < n; k += NT) A.ss[(long long)r * n + k] = sm.sspk[k];
+  if (tid == 0) A.status[r] = status;
+}
+
+}  // namespace drna

@@ -1,0 +1,249 @@
+// fold_pf.hpp -- McCaskill partition function (inside only) for one sequence per workgroup on gfx950.
+// Replaces fc.pf()[1] with md.compute_bpp = 0: reference utils/energy_scores.py:27-28,150.
+// Recursions, pf_smooth'ed dangle factors and per-nucleotide scaling: SURVEY.md App. A.5.
+//
+// Same anti-diagonal / lane-per-cell / diagonal-major design as fold_mfe.hpp with (+,x) in fp64
+// instead of (min,+) in int32.  Differences worth knowing:
+//   * only Z is needed, so the exterior recursion is the 1-D q5[j] (not ViennaRNA's full q[i,j]);
+//     B_alg for the PF half is therefore the "q5 only" figure of SURVEY 8(d);
+//   * qm[i,j] = qm1[i,j] + D[i,j] + U[i,j] with D[i,j] = sum_k qm[i,k-1] qm1[k,j] (the O(n^3) part;
+//     D[i+1,j-1] is also the multiloop term of qb[i,j]) and U[i,j] = sum_k expMLbase^(k-i) qm1[k,j]
+//     carried by the O(1) recurrence U[i,j] = b (qm1[i+1,j] + U[i+1,j]);
+//   * partial sums of a cell are combined in a fixed order, so results are bit-reproducible.
+#pragma once
+#include "fold_common.hpp"
+
+namespace drna {
+
+struct PfArgs {
+  const PfTables* T;
+  const Plan* plan;
+  const double* hp_w;          // hairpin Boltzmann factor by size (scale[u+2] folded in)
+  const double* scale;         // pf_scale^-k
+  const double* eMLb;          // (expMLbase / pf_scale)^k
+  const char* seqs;            // R x L ASCII
+  int L;
+  int ld;
+  double* ws;                  // per sequence 7 tables of ld*ld doubles + 1 of ld*ld bytes (as doubles/8)
+  long long ws_stride;         // doubles per sequence
+  double* Epf;                 // R  (kcal/mol)
+  int32_t* status;             // R
+};
+
+struct PfSmem {
+  double stack[64];
+  double mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128];
+  double int11[1024];
+  double d5[32], d3[32];
+  double partI[PART_ITEMS * WAVE];
+  double partK[PART_ITEMS * WAVE];
+  double q5[MAXN + 2];
+  unsigned char S[MAXN + 4];
+  int flag;
+};
+
+__device__ __forceinline__ double pf_hairpin(const PfSmem& sm, const PfArgs& A, int i, int j, int t) {
+  const PfTables& T = *A.T;
+  const int u = j - i - 1;
+  const double q = A.hp_w[u];
+  if (u == 3) {
+    if (T.n_tri) {
+      int code = 0;
+      for (int k = 0; k < 5; k++) code |= sm.S[i + k] << (2 * k);
+      for (int k = 0; k < T.n_tri; k++)
+        if (T.tri_code[k] == code) return T.tri_w[k] * A.scale[u + 2];
+    }
+    return t > 2 ? q * T.TermAU : q;
+  }
+  if (u == 4 && T.n_tetra) {
+    int code = 0;
+    for (int k = 0; k < 6; k++) code |= sm.S[i + k] << (2 * k);
+    for (int k = 0; k < T.n_tetra; k++)
+      if (T.tetra_code[k] == code) return T.tetra_w[k] * A.scale[u + 2];
+  } else if (u == 6 && T.n_hexa) {
+    int code = 0;
+    for (int k = 0; k < 8; k++) code |= sm.S[i + k] << (2 * k);
+    for (int k = 0; k < T.n_hexa; k++)
+      if (T.hexa_code[k] == code) return T.hexa_w[k] * A.scale[u + 2];
+  }
+  return q * sm.mmH[t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1]];
+}
+
+// exp_E_ExtLoop / exp_E_MLstem neighbour rule: a neighbour exists only inside the sequence
+__device__ __forceinline__ double pf_endstem(const double* mm, const PfSmem& sm, int t, int i, int j, int n) {
+  if (i > 1 && j < n) return mm[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]];
+  if (i > 1) return sm.d5[t * 4 + sm.S[i - 1]];
+  if (j < n) return sm.d3[t * 4 + sm.S[j + 1]];
+  return 1.0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
+  __shared__ PfSmem sm;
+  constexpr int NW = NT / WAVE;
+  const PfTables& T = *A.T;
+  const Plan& P = *A.plan;
+  const int r = blockIdx.x;
+  const int n = A.L, ld = A.ld;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  const int segG = P.seg[PK_GENERIC];
+
+  double* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  double* QB = base;
+  double* QBI = base + tab;
+  double* QM = base + 2 * tab;
+  double* QM1 = base + 3 * tab;
+  double* DQ = base + 4 * tab;
+  double* UQ = base + 5 * tab;
+  double* QEXT = base + 6 * tab;
+  unsigned char* INFO = reinterpret_cast<unsigned char*>(base + 7 * tab);
+
+  for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
+  for (int k = tid; k < 128; k += NT) {
+    sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
+    sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
+  }
+  for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
+  for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  if (tid == 0) sm.flag = 0;
+  __syncthreads();
+  const char* seq = A.seqs + (long long)r * n;
+  for (int k = tid; k < n; k += NT) {
+    const int c = enc_nt(seq[k]);
+    if (c < 0) sm.flag = 1;
+    sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
+  }
+  // rows read before they are written (all zero): qm1 / U diag 3, D diags 2 and 3
+  for (int k = tid; k < ld; k += NT) {
+    QM1[3 * ld + k] = 0.0; UQ[3 * ld + k] = 0.0;
+    DQ[2 * ld + k] = 0.0; DQ[3 * ld + k] = 0.0;
+  }
+  __syncthreads();
+  if (tid == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
+  __syncthreads();
+  if (sm.flag) {
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Epf[r] = 0.0; }
+    return;
+  }
+  const double b1 = A.eMLb[1];
+  const double sc2 = A.scale[2];
+
+  for (int d = TURN + 1; d < n; d++) {
+    const int ncell = n - d;
+    const int nblk = (ncell + WAVE - 1) / WAVE;
+    int H = NW / nblk;
+    if (H < 1) H = 1;
+    const int nitems = nblk * H;
+
+    for (int item = wave; item < nitems; item += NW) {
+      const int b = item / H, h = item - b * H;
+      const int i0 = b * WAVE + lane + 1;
+      const bool act = i0 <= ncell;
+      const int i = act ? i0 : ncell;
+      const int j = i + d;
+      const int t = pair_type(sm.S[i], sm.S[j]);
+      const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+      const int ij = t * 16 + si1 * 4 + sj1;
+      double accI = 0.0;
+      if (__ballot(act && t != 0) != 0ull) {
+        const double tau = t > 2 ? T.TermAU : 1.0;
+        for (int e = h; e < segG; e += H) {
+          const int u1 = P.u1[e], u2 = P.u2[e];
+          const int dp = d - 2 - u1 - u2;
+          if (dp <= TURN) continue;
+          const int at = dp * ld + i + 1 + u1;
+          const double qpq = QB[at];
+          const int info = INFO[at], t2 = info >> 4;
+          double f;
+          switch (P.kind[e]) {
+            case PK_STACK: f = sm.stack[t * 8 + t2]; break;
+            case PK_BULGE1: f = sm.stack[t * 8 + t2]; break;
+            case PK_BULGEN: f = tau * (t2 > 2 ? T.TermAU : 1.0); break;
+            case PK_INT11: f = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+            case PK_INT21: f = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
+            case PK_INT12: f = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
+            case PK_1XN: f = sm.mm1n[ij] * sm.mm1n[info]; break;
+            case PK_INT22:
+              f = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
+              break;
+            default: /* PK_INT23 */ f = sm.mm23[ij] * sm.mm23[info]; break;
+          }
+          accI += qpq * f * P.W[e];
+        }
+        double accG = 0.0;
+        for (int e = segG + h; e < NPLAN; e += H) {
+          const int u1 = P.u1[e];
+          const int dp = d - 2 - u1 - P.u2[e];
+          if (dp <= TURN) continue;
+          accG += QBI[dp * ld + i + 1 + u1] * P.W[e];
+        }
+        accI += accG * sm.mmI[ij];
+      }
+      double accK = 0.0;
+      for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
+        accK += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
+      sm.partI[item * WAVE + lane] = accI;
+      sm.partK[item * WAVE + lane] = accK;
+    }
+    __syncthreads();
+
+    for (int i = tid + 1; i <= ncell; i += NT) {
+      const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
+      double aI = 0.0, aK = 0.0;
+      for (int h = 0; h < H; h++) {
+        aI += sm.partI[(b * H + h) * WAVE + ln];
+        aK += sm.partK[(b * H + h) * WAVE + ln];
+      }
+      const int j = i + d;
+      const int t = pair_type(sm.S[i], sm.S[j]);
+      const double tau = t > 2 ? T.TermAU : 1.0;
+      double qb = 0.0;
+      int info = 0;
+      if (t) {
+        qb = pf_hairpin(sm, A, i, j, t) + aI;
+        qb += DQ[(d - 2) * ld + i + 1] * T.MLclosing * T.MLintern * tau *
+              sm.mmM[rtype_of(t) * 16 + sm.S[j - 1] * 4 + sm.S[i + 1]] * sc2;
+        info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
+      }
+      const int at = d * ld + i;
+      QB[at] = qb;
+      QBI[at] = qb * sm.mmI[info];
+      INFO[at] = (unsigned char)info;
+      QEXT[j * ld + i] = t ? qb * tau * pf_endstem(sm.mmExt, sm, t, i, j, n) : 0.0;
+      double m1 = QM1[(d - 1) * ld + i] * b1;
+      if (t) m1 += qb * T.MLintern * tau * pf_endstem(sm.mmM, sm, t, i, j, n);
+      const double U = b1 * (QM1[(d - 1) * ld + i + 1] + UQ[(d - 1) * ld + i + 1]);
+      QM1[at] = m1;
+      UQ[at] = U;
+      DQ[at] = aK;
+      QM[at] = m1 + aK + U;
+    }
+    __syncthreads();
+  }
+
+  // exterior: q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j)
+  if (wave == 0) {
+    const double sc1 = A.scale[1];
+    sm.q5[0] = 1.0;                         // every lane stores the same value
+    for (int j = 1; j <= n; j++) {
+      double s = 0.0;
+      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) s += sm.q5[i - 1] * QEXT[j * ld + i];
+      s = wave_sum_f64(s);
+      sm.q5[j] = sm.q5[j - 1] * sc1 + s;    // every lane stores the same value
+    }
+    if (lane == 0) {
+      const double Z = sm.q5[n];
+      if (!(Z > 0.0) || !(Z < 1.0e300)) {
+        A.status[r] = ST_PF_RANGE;
+        A.Epf[r] = 0.0;
+      } else {
+        A.status[r] = ST_OK;
+        A.Epf[r] = (-log(Z) - (double)n * log(T.pf_scale)) * T.kT / 1000.0;
+      }
+    }
+  }
+}
+
+}  // namespace drna

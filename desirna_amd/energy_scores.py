@@ -1,0 +1,210 @@
+"""Scoring function of the design loop, batched over replicas and backed by the gfx950 engine.
+
+Counterpart of the reference's ``utils/energy_scores.py``: ``score_sequence`` (:31-125),
+``get_mfe_e_ss`` (:128-159) and ``ScoreSeq`` (:162-450).  The ``-sf`` plug-in surface is unchanged:
+the same term names (``Ed-Epf``, ``1-MCC``, ``sln_Epf``, ``Ed-MFE``, ``1-precision``, ``1-recall``,
+``Edef``) with the same weights and x10 factors (:376-398), the alt-structure term (:98-102) and the
+motif bonus (:121-123, :443-450).  What changes is where the numbers come from: one
+``Engine.score_batch`` call returns Epf, the MFE (or pk-annotated) structure, the MFE energy and
+E(target), E(alt targets) for every replica of the batch, instead of 3-8 ViennaRNA calls per
+sequence inside a forked worker.
+
+Out of scope here: two-strand inputs (``oligo_state`` homodimer / heterodimer /
+avoid) and ``-nd on`` sub-optimal search -- they raise NotImplementedError rather than silently
+giving different numbers.
+"""
+from . import engine as _engine
+from .sim_score import batch_metrics
+
+AVAILABLE_SCORING_FUNCTIONS = ['Ed-Epf', '1-MCC', 'sln_Epf', 'Ed-MFE', '1-precision', '1-recall', 'Edef']
+
+
+def parse_scoring_functions(scoring_f_str, first_term_only=True):
+    """``-sf`` string -> [(name, weight), ...].
+
+    ``first_term_only=True`` reproduces the reference, whose ``return`` sits inside the loop
+    (``utils/stats_inputs_outputs.py:232-237``): only the first term survives.
+    """
+    out = []
+    for item in scoring_f_str.split(','):
+        if ':' not in item:
+            raise ValueError(f"Invalid scoring function format: {item}. Expected format: 'function:weight'")
+        function, weight = item.split(':')
+        out.append((function, float(weight)))
+        if first_term_only:
+            return out
+    return out
+
+
+class ScoreSeq:
+    """Per-replica state record; attribute names and order are the reference's (``vars(obj)`` is its CSV schema)."""
+
+    def __init__(self, sequence):
+        self.sequence = sequence
+        self.scoring_function = 0
+        self.replica_num = None
+        self.temp_shelf = None
+        self.sim_step = 0
+        self.edesired_minus_Epf = 0
+        self.Epf = 0
+        self.edesired = 0
+        self.mcc = 0
+        self.mcc_alt = 0
+        self.mfe_ss = None
+        self.subopt_e = 0
+        self.esubopt_minus_Epf = 0
+        self.sln_Epf = 0
+        self.MFE = 0
+        self.edesired_minus_MFE = 0
+        self.recall = 0
+        self.precision = 0
+        self.edesired2 = 0
+        self.edesired2_minus_Epf = 0
+
+    # setters with the reference's names
+    def get_replica_num(self, rep_num):
+        self.replica_num = rep_num
+
+    def get_temp_shelf(self, temp):
+        self.temp_shelf = temp
+
+    def get_sim_step(self, step):
+        self.sim_step = step
+
+    def get_Epf(self, Epf):
+        self.Epf = Epf
+
+    def get_mfe_ss(self, ss):
+        self.mfe_ss = ss
+
+    def get_edesired(self, e_target):
+        self.edesired = e_target
+
+    def get_edesired_minus_Epf(self, Epf, e_target):
+        self.edesired_minus_Epf = e_target - Epf
+
+    def get_edesired2(self, e_target):
+        self.edesired2 = e_target
+
+    def get_edesired2_minus_Epf(self, Epf, e_target):
+        self.edesired2_minus_Epf = e_target - Epf
+
+    def get_precision(self, precision):
+        self.precision = 1 - precision
+
+    def get_recall(self, recall):
+        self.recall = 1 - recall
+
+    def get_mcc(self, mcc):
+        self.mcc = 1 - mcc
+
+    def get_sln_Epf(self):
+        self.sln_Epf = (self.Epf + 0.3759 * len(self.sequence) + 5.7534) / 10
+
+    def get_MFE(self, mfe):
+        """reference :350-354 re-folds with RNA.fold(); the engine's fill already produced f5[n]."""
+        self.MFE = mfe
+
+    def get_edesired_minus_MFE(self):
+        self.edesired_minus_MFE = self.edesired - self.MFE
+
+    def get_scoring_function(self, scoring_f):
+        self.scoring_function = 0
+        for function, weight in scoring_f:
+            if function == 'Ed-Epf':
+                self.scoring_function += self.edesired_minus_Epf * weight
+            elif function == '1-MCC':
+                self.scoring_function += self.mcc * 10 * weight
+            elif function == 'sln_Epf':
+                self.scoring_function += self.sln_Epf * weight
+            elif function == 'Ed-MFE':
+                self.scoring_function += self.edesired_minus_MFE * weight
+            elif function == '1-precision':
+                self.scoring_function += self.precision * 10 * weight
+            elif function == '1-recall':
+                self.scoring_function += self.recall * 10 * weight
+            elif function == 'Edef':
+                self.scoring_function += self.ensemble_defect * weight
+
+    def get_scoring_function_w_alt_ss(self):
+        self.scoring_function = self.scoring_function + self.edesired2_minus_Epf
+
+    def update_scoring_function_w_motifs(self, motif_bonus):
+        self.scoring_function += motif_bonus
+
+
+def score_motifs(seq, sim_options):
+    """reference utils/sequence_utils.py:1231-1251"""
+    motif_score = 0
+    for motif in sim_options.motifs:
+        if sim_options.motifs[motif][0].search(seq):
+            motif_score += sim_options.motifs[motif][1]
+    return motif_score
+
+
+class ReplicaScorer:
+    """Binds an engine to one design problem (target + alt structures + options) and scores batches."""
+
+    def __init__(self, input_file, sim_options, max_replicas, device=0, engine=None):
+        if getattr(sim_options, "oligo_state", "none") != "none":
+            raise NotImplementedError("two-strand scoring (oligo_state=%r) is not part of the GPU path yet"
+                                      % sim_options.oligo_state)
+        if getattr(sim_options, "subopt", "off") == "on":
+            raise NotImplementedError("-nd on (sub-optimal search) is not part of the GPU path")
+        self.input_file = input_file
+        self.sim_options = sim_options
+        self.target = input_file.sec_struct.replace("&", "")
+        L = len(self.target)
+        self.engine = engine or _engine.Engine(max_R=max_replicas, max_L=L, device=device,
+                                               params=str(getattr(sim_options, "param", "1999")))
+        targets = [self.target]
+        if getattr(input_file, "alt_sec_struct", None) is not None:
+            targets += [a.replace("&", "") for a in input_file.alt_sec_structs]
+        self.engine.set_targets(targets)
+        self.flags = _engine.NEED_PF | _engine.NEED_MFE | _engine.NEED_EVAL
+        if getattr(sim_options, "pks", "off") == "on":
+            self.flags |= _engine.NEED_PK
+        for function, _ in sim_options.scoring_f:
+            if function not in AVAILABLE_SCORING_FUNCTIONS:
+                raise ValueError("%s is not an available option for scoring function. Check your command." % function)
+            if function == 'Edef':
+                raise NotImplementedError("Edef (ensemble defect) needs the outside recursion: not on the GPU path yet")
+
+    def score(self, seqs):
+        """list of sequences -> list of ScoreSeq (reference score_sequence(), once per replica)."""
+        out = self.engine.score_batch(list(seqs), self.flags)
+        metrics = batch_metrics(self.input_file.sec_struct.replace("&", "Ee"),
+                                [s.replace("&", "Ee") for s in out["mfe_ss"]])
+        res = []
+        for k, seq in enumerate(seqs):
+            sc = ScoreSeq(sequence=seq)
+            sc.get_Epf(float(out["Epf"][k]))
+            sc.get_mfe_ss(out["mfe_ss"][k])
+            sc.get_edesired(int(out["Ed"][k, 0]) / 100.0)
+            sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
+            mcc, recall, precision = metrics[k]
+            sc.get_precision(precision)
+            sc.get_recall(recall)
+            sc.get_mcc(mcc)
+            for function, _ in self.sim_options.scoring_f:
+                if function == 'sln_Epf':
+                    sc.get_sln_Epf()
+                if function == 'Ed-MFE':
+                    sc.get_MFE(int(out["Emfe"][k]) / 100.0)
+                    sc.get_edesired_minus_MFE()
+            sc.get_scoring_function(self.sim_options.scoring_f)
+            if getattr(self.input_file, "alt_sec_struct", None) is not None:
+                energies = [int(e) / 100.0 for e in out["Ed"][k, 1:]]
+                sc.get_edesired2(sum(energies) / len(energies))
+                sc.get_edesired2_minus_Epf(sc.Epf, sc.edesired2)
+                sc.get_scoring_function_w_alt_ss()
+            if getattr(self.sim_options, "motifs", None):
+                sc.update_scoring_function_w_motifs(score_motifs(seq, self.sim_options))
+            res.append(sc)
+        return res
+
+
+def score_sequence(seq, input_file, sim_options, scorer=None):
+    """Single-sequence form with the reference's signature (a batch of one)."""
+    scorer = scorer or ReplicaScorer(input_file, sim_options, max_replicas=1)
+    return scorer.score([seq])[0]

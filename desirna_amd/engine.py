@@ -1,0 +1,134 @@
+"""ctypes binding of the gfx950 scoring engine (include/desirna_amd.h -> libdesirna_amd.so).
+
+This is the Python side of the drop-in boundary: what the reference gets from the ViennaRNA SWIG
+module per sequence (``RNA.fold_compound(seq, md).pf() / .mfe() / .eval_structure()``, reference
+``utils/energy_scores.py:147-151,75``) is obtained here for a whole batch of replicas per call.
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU is present the
+constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import params as _params
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdesirna_amd.so")
+
+NEED_PF, NEED_MFE, NEED_PK, NEED_EVAL = 1, 2, 4, 8
+
+_ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error", -4: "bad sequence character",
+           -5: "unbalanced structure", -6: "partition function out of fp64 range", -7: "internal (traceback)"}
+
+EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
+           "drna_score_batch_device", "drna_last_timing", "drna_info")
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("desirna_amd engine error %d (%s): %s" % (code, _ERRORS.get(code, "?"), msg))
+        self.code = code
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and declare its signatures (raises if it has not been built)."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C desirna_amd/csrc`); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, ci, u32 = C.c_void_p, C.c_int, C.c_uint32
+    L.drna_create.restype = ci
+    L.drna_create.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
+    L.drna_destroy.restype = None
+    L.drna_destroy.argtypes = [vp]
+    L.drna_last_error.restype = C.c_char_p
+    L.drna_last_error.argtypes = [vp]
+    L.drna_set_targets.restype = ci
+    L.drna_set_targets.argtypes = [vp, ci, ci, C.c_char_p]
+    L.drna_score_batch.restype = ci
+    L.drna_score_batch.argtypes = [vp, ci, ci, C.c_char_p, u32, vp, vp, vp, vp]
+    L.drna_score_batch_device.restype = ci
+    L.drna_score_batch_device.argtypes = [vp, ci, ci, vp, u32, vp, vp, vp, vp]
+    L.drna_last_timing.restype = ci
+    L.drna_last_timing.argtypes = [vp, vp]
+    L.drna_info.restype = ci
+    L.drna_info.argtypes = [vp, vp]
+    return L
+
+
+class Engine:
+    """One engine per GPU (``RNA.params_load`` + all ``RNA.fold_compound`` allocations, done once)."""
+
+    def __init__(self, max_R, max_L, device=0, params="1999", lib=None):
+        self._L = load_library(lib)
+        self._h = C.c_void_p()
+        blob = params if isinstance(params, np.ndarray) else _params.load_params(params)
+        blob = np.ascontiguousarray(blob, dtype=np.int32)
+        rc = self._L.drna_create(blob.ctypes.data, blob.size, int(device), int(max_R), int(max_L), C.byref(self._h))
+        if rc != 0:
+            raise EngineError(rc, self._L.drna_last_error(None).decode())
+        self.max_R, self.max_L, self.device = int(max_R), int(max_L), int(device)
+        self.n_targets = 0
+        self.L = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.drna_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self._L.drna_last_error(self._h).decode())
+
+    def set_targets(self, targets):
+        """targets[0] = design target, targets[1:] = alternative structures ('&' already removed)."""
+        targets = list(targets)
+        L = len(targets[0]) if targets else 1
+        if any(len(t) != L for t in targets):
+            raise ValueError("all target structures must have the same length")
+        self._check(self._L.drna_set_targets(self._h, len(targets), L, "".join(targets).encode("ascii")))
+        self.n_targets, self.L = len(targets), L
+
+    def score_batch(self, seqs, flags=NEED_PF | NEED_MFE | NEED_EVAL):
+        """seqs: list of equal-length strings.  Returns dict(Epf, Emfe, mfe_ss, Ed) (None if not requested);
+        energies in ViennaRNA's units: Epf kcal/mol (float), Emfe / Ed int dcal/mol."""
+        R = len(seqs)
+        L = len(seqs[0])
+        if any(len(s) != L for s in seqs):
+            raise ValueError("all sequences of a batch must have the same length")
+        sb = "".join(seqs).encode("ascii")
+        Epf = np.zeros(R, dtype=np.float64) if flags & NEED_PF else None
+        want_mfe = flags & (NEED_MFE | NEED_PK)
+        Emfe = np.zeros(R, dtype=np.int32) if want_mfe else None
+        ss = np.zeros((R, L), dtype=np.uint8) if want_mfe else None
+        Ed = np.zeros((R, max(1, self.n_targets)), dtype=np.int32) if flags & NEED_EVAL else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.drna_score_batch(self._h, R, L, sb, flags, ptr(Epf), ptr(Emfe), ptr(ss), ptr(Ed)))
+        return {"Epf": Epf, "Emfe": Emfe,
+                "mfe_ss": [bytes(r).decode("ascii") for r in ss] if ss is not None else None, "Ed": Ed}
+
+    def score_batch_device(self, d_seqs, R, L, flags, d_Epf=None, d_Emfe=None, d_ss=None, d_Ed=None):
+        """Device-resident variant: arguments are raw device pointers (e.g. ``tensor.data_ptr()``).
+        The caller must have made the inputs visible (``torch.cuda.synchronize()``) before the call."""
+        self._check(self._L.drna_score_batch_device(self._h, R, L, d_seqs, flags, d_Epf, d_Emfe, d_ss, d_Ed))
+
+    def last_timing(self):
+        """ms of device time of the last call: dict(mfe, pf, eval, total) from HIP events on the engine's streams."""
+        out = (C.c_float * 4)()
+        self._check(self._L.drna_last_timing(self._h, out))
+        return {"mfe": out[0], "pf": out[1], "eval": out[2], "total": out[3]}
+
+    def info(self):
+        out = (C.c_int64 * 6)()
+        self._check(self._L.drna_info(self._h, out))
+        return {"device": out[0], "max_R": out[1], "max_L": out[2], "threads_per_wg": out[3],
+                "compute_units": out[4], "workspace_bytes": out[5]}

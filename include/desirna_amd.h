@@ -1,0 +1,106 @@
+/*
+ * desirna_amd.h -- C ABI of the MI355X (gfx950) replica-scoring engine.
+ *
+ * This is the drop-in boundary for the one hot path of fryzjergda/DesiRNA: scoring every mutated
+ * sequence of every replica.  The reference has no FFI of its own; its de-facto operator boundary
+ * is the set of ViennaRNA SWIG calls made per sequence by utils/energy_scores.py.
+ * Each entry point below names the reference call sites it replaces (paths relative to the
+ * reference tree).  Plain C types only; every buffer is owned by the caller; a handle is bound to
+ * one GPU and must be used from one host thread at a time.
+ *
+ * Units: integer energies are dcal/mol (0.01 kcal/mol) exactly as ViennaRNA keeps them internally
+ * (the Python shim divides by 100 to reproduce ViennaRNA's float returns); Epf is kcal/mol.
+ * Sequences are upper- or lower-case A C G U (T is read as U); structures are dot-bracket strings
+ * in which only '(' and ')' denote pairs for energy evaluation.
+ */
+#ifndef DESIRNA_AMD_H
+#define DESIRNA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct drna_engine drna_engine;
+
+/* return codes */
+enum {
+  DRNA_OK = 0,
+  DRNA_ERR_ARG = -1,        /* null pointer, R/L out of range, bad flags                    */
+  DRNA_ERR_PARAMS = -2,     /* malformed parameter blob                                     */
+  DRNA_ERR_DEVICE = -3,     /* HIP error (no device, out of memory, launch failure)         */
+  DRNA_ERR_SEQUENCE = -4,   /* a sequence holds a character other than A C G U T            */
+  DRNA_ERR_STRUCTURE = -5,  /* unbalanced '(' ')' in a target structure                     */
+  DRNA_ERR_PF_RANGE = -6,   /* partition function left the fp64 range despite scaling       */
+  DRNA_ERR_INTERNAL = -7    /* traceback could not reproduce a table value (engine bug)     */
+};
+
+/* what drna_score_batch computes */
+enum {
+  DRNA_NEED_PF = 1u,          /* Epf            : fc.pf()            energy_scores.py:150           */
+  DRNA_NEED_MFE = 2u,         /* mfe_ss + Emfe  : fc.mfe()           energy_scores.py:151, :354     */
+  DRNA_NEED_PK = 4u,          /* pk annotation  : get_pk_struct()    sequence_utils.py:1166-1228    */
+  DRNA_NEED_EVAL = 8u         /* Ed             : fc.eval_structure  energy_scores.py:75, :99       */
+};
+
+/*
+ * Create an engine on HIP device `device`.
+ * Replaces RNA.params_load(path) (DesiRNA.py:455-456) and the per-call table allocation of
+ * RNA.fold_compound(seq, md) (energy_scores.py:147): parameters are expanded once into device
+ * tables, workspaces are sized once for max_R sequences of at most max_L nucleotides.
+ * `params` is the int32 blob produced by desirna_amd/params.py (layout documented there).
+ */
+int drna_create(const int32_t *params, int n_int32, int device, int max_R, int max_L, drna_engine **out);
+
+void drna_destroy(drna_engine *e);
+
+/* message for the last non-OK return on this engine (or for a failed drna_create when e == NULL) */
+const char *drna_last_error(const drna_engine *e);
+
+/*
+ * Install the target structure(s) every sequence is evaluated against: targets[0] is the design
+ * target (input file >sec_struct, '&' removed), targets[1..] the >alt_sec_struct lines.
+ * Replaces the argument of fc.eval_structure(...) at energy_scores.py:75 and :99.
+ * `targets` holds n_targets strings of exactly L characters, back to back (no terminators).
+ */
+int drna_set_targets(drna_engine *e, int n_targets, int L, const char *targets);
+
+/*
+ * Score R sequences of length L (host buffers).  Replaces, for all R replicas at once, the
+ * ViennaRNA calls of score_sequence(): get_mfe_e_ss (energy_scores.py:128-159), eval_structure
+ * (:75,:99), RNA.fold(seq)[1] (:354) and get_pk_struct (sequence_utils.py:1166-1228).
+ *   seqs    R*L chars                                   in
+ *   flags   OR of DRNA_NEED_*                           in
+ *   Epf     R doubles, kcal/mol                         out (NEED_PF)      may be NULL otherwise
+ *   Emfe    R int32, dcal/mol                           out (NEED_MFE)
+ *   mfe_ss  R*L chars, no terminators                   out (NEED_MFE; pk-annotated with NEED_PK)
+ *   Ed      R*n_targets int32, dcal/mol                 out (NEED_EVAL; needs drna_set_targets)
+ */
+int drna_score_batch(drna_engine *e, int R, int L, const char *seqs, uint32_t flags,
+                     double *Epf, int32_t *Emfe, char *mfe_ss, int32_t *Ed);
+
+/*
+ * Same with every buffer already resident in device memory (e.g. torch tensors on the engine's
+ * device).  Work is enqueued on the engine's streams and the call returns after they have drained.
+ * status (device, R int32, may be NULL) receives per-sequence status words.
+ */
+int drna_score_batch_device(drna_engine *e, int R, int L, const char *d_seqs, uint32_t flags,
+                            double *d_Epf, int32_t *d_Emfe, char *d_mfe_ss, int32_t *d_Ed);
+
+/*
+ * Timing hook for bench.py: average device time in milliseconds of the most recent
+ * drna_score_batch*_ call, per kernel family, measured with HIP events on the engine's own
+ * streams.  out[0] = MFE fill+traceback kernel, out[1] = PF kernel, out[2] = eval kernel,
+ * out[3] = whole call (first launch to last completion).
+ */
+int drna_last_timing(const drna_engine *e, float out[4]);
+
+/* engine facts: out[0]=device, out[1]=max_R, out[2]=max_L, out[3]=threads per workgroup,
+ * out[4]=compute units, out[5]=bytes of device workspace */
+int drna_info(const drna_engine *e, int64_t out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

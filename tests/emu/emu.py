@@ -1,0 +1,73 @@
+"""ctypes loader for the TEST-ONLY CPU emulation of the HIP kernels (tests/emu/)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libemu.so")
+_CSRC = os.path.join(_HERE, "..", "..", "desirna_amd", "csrc")
+
+
+def build():
+    srcs = [os.path.join(_HERE, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
+    srcs += [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hpp")]
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", _LIB,
+                               os.path.join(_HERE, "emu_kernels.cpp")])
+    L = C.CDLL(_LIB)
+    vp, ci = C.c_void_p, C.c_int
+    L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
+    L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
+    L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
+    return L
+
+
+class Emu:
+    def __init__(self, blob):
+        self.L = build()
+        self.blob = np.ascontiguousarray(blob, dtype=np.int32)
+
+    def mfe(self, seqs, pk_rounds=0, nt=128, dump=False):
+        R, L = len(seqs), len(seqs[0])
+        sb = "".join(seqs).encode()
+        E = np.zeros(R, dtype=np.int32)
+        ss = np.zeros((R, L), dtype=np.uint8)
+        st = np.zeros(R, dtype=np.int32)
+        ld = L + 2
+        Wc = np.zeros((ld, ld), dtype=np.int32) if dump else None
+        F = np.zeros((ld, ld), dtype=np.int32) if dump else None
+        rc = self.L.emu_mfe(self.blob.ctypes.data, self.blob.size, R, L, sb, pk_rounds, nt, E.ctypes.data,
+                            ss.ctypes.data, st.ctypes.data, Wc.ctypes.data if dump else None,
+                            F.ctypes.data if dump else None)
+        assert rc == 0
+        out = (E, [bytes(r).decode() for r in ss], st)
+        return out + (Wc, F) if dump else out
+
+    def pf(self, seqs, nt=128):
+        R, L = len(seqs), len(seqs[0])
+        E = np.zeros(R)
+        st = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_pf(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), nt,
+                           E.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        return E, st
+
+    def eval(self, seqs, targets):
+        R, L = len(seqs), len(seqs[0])
+        pt = np.zeros((len(targets), L + 2), dtype=np.int16)
+        for k, t in enumerate(targets):
+            stk = []
+            for i, ch in enumerate(t, 1):
+                if ch == "(":
+                    stk.append(i)
+                elif ch == ")":
+                    o = stk.pop()
+                    pt[k, o] = i
+                    pt[k, i] = o
+        Ed = np.zeros((R, len(targets)), dtype=np.int32)
+        rc = self.L.emu_eval(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), len(targets),
+                             pt.ctypes.data, Ed.ctypes.data)
+        assert rc == 0
+        return Ed

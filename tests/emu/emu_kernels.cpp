@@ -1,0 +1,90 @@
+// emu_kernels.cpp -- TEST-ONLY: compiles the unmodified kernel headers against hip_emu.h and exposes
+// them through a tiny C interface for tests/test_kernels_emulated.py (CPU, no GPU needed).
+#include "hip_emu.h"
+
+thread_local emu_dim3 threadIdx;
+emu_dim3 blockIdx;
+emu_group* emu_g = nullptr;
+
+#include "../../desirna_amd/csrc/eval_structure.hpp"
+#include "../../desirna_amd/csrc/fold_mfe.hpp"
+#include "../../desirna_amd/csrc/fold_pf.hpp"
+
+using namespace drna;
+
+namespace {
+struct Ctx {
+  HostTables H;
+  bool ok = false;
+};
+Ctx* make_ctx(const int32_t* blob, int n, int max_L) {
+  Ctx* c = new Ctx();
+  c->ok = build_tables(blob, n, c->H).empty();
+  if (c->ok) size_tables(c->H, max_L + 2);
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+// returns 0 on success.  tables (optional, may be null): Wc / FML dumps of the LAST sequence, ld*ld int32 each
+int emu_mfe(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int pk_rounds, int nt, int32_t* Emfe,
+            char* ss, int32_t* status, int32_t* dumpWc, int32_t* dumpFML) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  std::vector<int32_t> ws((size_t)5 * ld * ld, 0);
+  for (int r = 0; r < R; r++) {
+    MfeArgs a;
+    a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data();
+    a.seqs = seqs; a.L = L; a.ld = ld; a.pk_rounds = pk_rounds;
+    a.ws = ws.data() - (size_t)r * 5 * ld * ld; a.ws_stride = (long long)5 * ld * ld;   // same buffer for every r
+    a.Emfe = Emfe; a.ss = ss; a.status = status;
+    auto fn = [&]() {
+      if (nt == 64) mfe_kernel<64>(a);
+      else if (nt == 128) mfe_kernel<128>(a);
+      else mfe_kernel<256>(a);
+    };
+    emu_launch(r, nt, fn);
+  }
+  if (dumpWc) std::memcpy(dumpWc, ws.data(), (size_t)ld * ld * 4);
+  if (dumpFML) std::memcpy(dumpFML, ws.data() + (size_t)2 * ld * ld, (size_t)ld * ld * 4);
+  delete c;
+  return 0;
+}
+
+int emu_pf(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int nt, double* Epf, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  const size_t stride = (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8;
+  std::vector<double> ws(stride, 0.0);
+  for (int r = 0; r < R; r++) {
+    PfArgs a;
+    a.T = &c->H.pf; a.plan = &c->H.plan; a.hp_w = c->H.hp_w.data(); a.scale = c->H.scale.data();
+    a.eMLb = c->H.eMLb.data(); a.seqs = seqs; a.L = L; a.ld = ld;
+    a.ws = ws.data() - (size_t)r * stride; a.ws_stride = (long long)stride;
+    a.Epf = Epf; a.status = status;
+    auto fn = [&]() {
+      if (nt == 64) pf_kernel<64>(a);
+      else if (nt == 128) pf_kernel<128>(a);
+      else pf_kernel<256>(a);
+    };
+    emu_launch(r, nt, fn);
+  }
+  delete c;
+  return 0;
+}
+
+int emu_eval(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int n_targets, const short* pt,
+             int32_t* Ed) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  EvalArgs a;
+  a.T = &c->H.mfe; a.hp_len = c->H.hp_len.data(); a.bulge_len = c->H.bulge_len.data(); a.int_len = c->H.int_len.data();
+  a.seqs = seqs; a.pt = pt; a.L = L; a.n_targets = n_targets; a.Ed = Ed;
+  for (int b = 0; b < R * n_targets; b++) emu_launch(b, 64, [&]() { eval_kernel(a); });
+  delete c;
+  return 0;
+}
+}

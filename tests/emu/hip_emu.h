@@ -1,0 +1,92 @@
+// hip_emu.h -- TEST-ONLY stand-in for the handful of HIP device constructs the fold kernels use, so
+// that the *unmodified* kernel sources (desirna_amd/csrc/*.hpp) can be compiled with g++ and their
+// logic checked against the oracle in a container that has no GPU.  One workgroup is emulated at a
+// time: every GPU thread is an OS thread, __syncthreads() is a real barrier, wave collectives
+// (__shfl_xor, __ballot) rendezvous the 64 lanes of a wave.  Nothing here is part of the product.
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct emu_dim3 { int x = 0, y = 0, z = 0; };
+extern thread_local emu_dim3 threadIdx;
+extern emu_dim3 blockIdx;
+
+struct emu_wave {
+  pthread_barrier_t bar;
+  unsigned long long slot[64];
+};
+struct emu_group {
+  pthread_barrier_t bar;
+  std::vector<emu_wave> waves;
+};
+extern emu_group* emu_g;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu_g->bar); }
+
+template <typename T>
+static inline T emu_exchange(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "emu_exchange: 8 bytes at most");
+  emu_wave& w = emu_g->waves[threadIdx.x >> 6];
+  unsigned long long raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  w.slot[threadIdx.x & 63] = raw;
+  pthread_barrier_wait(&w.bar);
+  unsigned long long got = w.slot[src_lane & 63];
+  pthread_barrier_wait(&w.bar);
+  T out;
+  std::memcpy(&out, &got, sizeof(T));
+  return out;
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask) { return emu_exchange(v, (threadIdx.x & 63) ^ mask); }
+template <typename T>
+static inline T __shfl(T v, int lane) { return emu_exchange(v, lane); }
+
+static inline unsigned long long __ballot(bool p) {
+  emu_wave& w = emu_g->waves[threadIdx.x >> 6];
+  w.slot[threadIdx.x & 63] = p ? 1ull : 0ull;
+  pthread_barrier_wait(&w.bar);
+  unsigned long long m = 0;
+  for (int k = 0; k < 64; k++) m |= (w.slot[k] & 1ull) << k;
+  pthread_barrier_wait(&w.bar);
+  return m;
+}
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+using std::min;
+using std::max;
+
+// run one workgroup of nt threads executing fn()
+static inline void emu_launch(int block, int nt, const std::function<void()>& fn) {
+  emu_group g;
+  g.waves.resize(nt / 64);
+  pthread_barrier_init(&g.bar, nullptr, nt);
+  for (auto& w : g.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+  emu_g = &g;
+  blockIdx.x = block;
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([t, &fn]() {
+      threadIdx.x = t;
+      fn();
+    });
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&g.bar);
+  for (auto& w : g.waves) pthread_barrier_destroy(&w.bar);
+  emu_g = nullptr;
+}

@@ -1,0 +1,176 @@
+"""GPU parity tests proper: HIP path through the C ABI (ctypes -> libdesirna_amd.so) against the CPU
+oracle and the committed golden vectors.  Integer quantities (MFE energy, E(target)) and bracket
+strings must be bit-exact; Epf must agree with the oracle to EPF_TOL_ORACLE and with the reference's
+float32 goldens to EPF_TOL_GOLDEN (north_star: 'stated fp tolerance')."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPF_TOL_ORACLE = 1e-9   # kcal/mol, fp64 summation-order differences only
+EPF_TOL_GOLDEN = 2e-6   # kcal/mol, goldens are float32
+TIE_OUTLIER = "GGUACAGCCGUGCCCCUUAGGGCACCGUGGUGUACC"
+SINGLE = ("Standard_design_input", "Seed_sequence_design_input",
+          "Alternative_structures_design_input", "Pseudoknot_design_input")
+
+
+@pytest.fixture(scope="module")
+def eng400():
+    from desirna_amd import engine
+    e = engine.Engine(max_R=128, max_L=400, device=0)
+    yield e
+    e.close()
+
+
+def _rand(rng, L, alphabet="ACGU"):
+    return "".join(rng.choice(list(alphabet), L))
+
+
+def _check_against_oracle(eng, oracle, seqs, targets, pk=False):
+    from desirna_amd import engine as E
+    eng.set_targets(targets)
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL | (E.NEED_PK if pk else 0)
+    out = eng.score_batch(seqs, flags)
+    for k, s in enumerate(seqs):
+        ss, e = oracle.mfe(s)
+        if pk:
+            ss = oracle.pk_struct(s, ss)
+        assert out["mfe_ss"][k] == ss, (s, out["mfe_ss"][k], ss)
+        assert int(out["Emfe"][k]) == e, s
+        assert abs(float(out["Epf"][k]) - oracle.pf(s)) < EPF_TOL_ORACLE, s
+        for t, tg in enumerate(targets):
+            assert int(out["Ed"][k, t]) == oracle.eval_structure(s, tg), (s, tg)
+    return out
+
+
+def test_library_loaded_is_in_tree():
+    from desirna_amd import engine
+    import os
+    assert os.path.exists(engine.LIB_PATH)
+    engine.load_library()
+
+
+def test_golden_trajectories(eng400, traj_golden, example_inputs):
+    from desirna_amd import engine as E
+    for run in SINGLE:
+        rows = [r for r in traj_golden if r["run"] == run]
+        inp = example_inputs[run]
+        targets = [inp["sec_struct"][0]] + inp.get("alt_sec_struct", [])
+        eng400.set_targets(targets)
+        pk = bool(int(rows[0]["pk_on"]))
+        flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL | (E.NEED_PK if pk else 0)
+        for b in range(0, len(rows), 128):
+            chunk = rows[b:b + 128]
+            out = eng400.score_batch([r["sequence"] for r in chunk], flags)
+            for k, r in enumerate(chunk):
+                assert abs(float(out["Epf"][k]) - float(r["Epf"])) < EPF_TOL_GOLDEN, r["sequence"]
+                assert int(out["Ed"][k, 0]) == round(float(r["edesired"]) * 100), r["sequence"]
+                if r["sequence"] != TIE_OUTLIER:
+                    assert out["mfe_ss"][k] == r["mfe_ss"], r["sequence"]
+                if len(targets) > 1:
+                    alt = [int(x) / 100.0 for x in out["Ed"][k, 1:]]
+                    assert abs(sum(alt) / len(alt) - float(r["edesired2"])) < 1e-5
+
+
+def test_eterna_v1_solutions(eng400, oracle, eterna_solutions):
+    from desirna_amd import engine as E
+    by_len = {}
+    for r in eterna_solutions:
+        by_len.setdefault(len(r["sequence"]), []).append(r)
+    for L, rows in by_len.items():
+        for r in rows:
+            eng400.set_targets([r["structure"]])
+            out = eng400.score_batch([r["sequence"]], E.NEED_PF | E.NEED_MFE | E.NEED_EVAL)
+            assert out["mfe_ss"][0] == r["structure"], r["name"]
+            assert int(out["Emfe"][0]) == int(out["Ed"][0, 0]), r["name"]
+            if L <= 200:
+                assert abs(float(out["Epf"][0]) - oracle.pf(r["sequence"])) < EPF_TOL_ORACLE
+
+
+@pytest.mark.parametrize("L,R", [(1, 3), (4, 2), (5, 4), (8, 4), (63, 8), (64, 8), (65, 8), (100, 16), (129, 8)])
+def test_random_vs_oracle(eng400, oracle, L, R):
+    rng = np.random.default_rng(1000 + L)
+    seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
+    _check_against_oracle(eng400, oracle, seqs, ["." * L])
+
+
+def test_config3_full_batch_vs_oracle(eng400, oracle, eterna_targets):
+    """BASELINE config 3: L=200 (Eterna V1 #69 target), R=64, uniform-random sequences, MFE+PF+eval."""
+    tg = eterna_targets["eteV1_69.txt"]
+    rng = np.random.default_rng(20260101)
+    seqs = [_rand(rng, len(tg)) for _ in range(64)]
+    _check_against_oracle(eng400, oracle, seqs, [tg])
+
+
+def test_config2_L100(eng400, oracle, eterna_targets):
+    tg = eterna_targets["eteV1_92.txt"]
+    rng = np.random.default_rng(2)
+    seqs = [_rand(rng, len(tg)) for _ in range(64)]
+    _check_against_oracle(eng400, oracle, seqs, [tg])
+
+
+def test_config5_L400_pk_alt(eng400, oracle, eterna_targets):
+    """L=400 with pk heuristic and alternative targets (two extra eval structures)."""
+    tg = eterna_targets["eteV1_53.txt"]
+    L = len(tg)
+    rng = np.random.default_rng(5)
+    seqs = [_rand(rng, L) for _ in range(6)] + [_rand(rng, L, "GGCCAU") for _ in range(2)]
+    alts = [eterna_targets["eteV1_22.txt"], eterna_targets["eteV1_63.txt"]]
+    assert all(len(a) == L for a in alts)
+    _check_against_oracle(eng400, oracle, seqs, [tg] + alts, pk=True)
+
+
+def test_properties_at_full_size(eng400, eterna_targets):
+    """Size-independent properties at R=128, L=200: E(MFE structure) == MFE energy, Epf <= MFE,
+    bit-identical results across two calls, and batch-composition independence."""
+    from desirna_amd import engine as E
+    L = 200
+    rng = np.random.default_rng(77)
+    seqs = [_rand(rng, L) for _ in range(128)]
+    eng400.set_targets(["." * L])
+    a = eng400.score_batch(seqs, E.NEED_PF | E.NEED_MFE)
+    b = eng400.score_batch(seqs, E.NEED_PF | E.NEED_MFE)
+    assert a["mfe_ss"] == b["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all()
+    assert (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all()
+    c = eng400.score_batch(seqs[::-1][:17], E.NEED_PF | E.NEED_MFE)
+    assert c["mfe_ss"] == a["mfe_ss"][::-1][:17]
+    assert (c["Epf"].view(np.int64) == a["Epf"][::-1][:17].view(np.int64)).all()
+    for k, s in enumerate(seqs):
+        eng400.set_targets([a["mfe_ss"][k]])
+        ed = eng400.score_batch([s], E.NEED_EVAL)["Ed"][0, 0]
+        assert int(ed) == int(a["Emfe"][k])
+        assert float(a["Epf"][k]) <= a["Emfe"][k] / 100.0 + 1e-9
+
+
+def test_errors(eng400):
+    from desirna_amd import engine as E
+    eng400.set_targets(["." * 10])
+    with pytest.raises(E.EngineError) as ei:
+        eng400.score_batch(["GGGAAANCCC"])
+    assert ei.value.code == -4
+    with pytest.raises(E.EngineError) as ei:
+        eng400.set_targets(["((..."])
+    assert ei.value.code == -5
+    with pytest.raises(E.EngineError) as ei:
+        eng400.score_batch(["A" * 401], E.NEED_MFE)
+    assert ei.value.code == -1
+
+
+def test_replica_scorer_matches_reference_fields(traj_golden, example_inputs):
+    """Host mirror of score_sequence(): ScoreSeq fields against the committed trajectory columns."""
+    from types import SimpleNamespace
+    from desirna_amd.energy_scores import ReplicaScorer, parse_scoring_functions
+    inp = example_inputs["Standard_design_input"]
+    input_file = SimpleNamespace(sec_struct=inp["sec_struct"][0], alt_sec_struct=None, alt_sec_structs=None)
+    opts = SimpleNamespace(oligo_state="none", pks="off", subopt="off", motifs=None, param="1999",
+                           scoring_f=parse_scoring_functions("Ed-Epf:1.0"))
+    rows = [r for r in traj_golden if r["run"] == "Standard_design_input"][:64]
+    sc = ReplicaScorer(input_file, opts, max_replicas=64)
+    res = sc.score([r["sequence"] for r in rows])
+    for r, s in zip(rows, res):
+        assert s.mfe_ss == r["mfe_ss"]
+        assert s.mcc == float(r["one_minus_mcc"]) and s.recall == float(r["one_minus_recall"])
+        assert s.precision == float(r["one_minus_precision"])
+        assert abs(s.Epf - float(r["Epf"])) < EPF_TOL_GOLDEN
+        assert abs(s.edesired - float(r["edesired"])) < 1e-6
+        assert abs(s.scoring_function - (s.edesired - s.Epf)) < 1e-12

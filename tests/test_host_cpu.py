@@ -1,0 +1,71 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_blob_matches_reference_file_when_present(blob):
+    ref = "/root/reference/rna_turner1999.par"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this box")
+    from desirna_amd import params
+    assert (params.load_par_file(ref) == blob).all()
+
+
+def test_blob_spot_values(blob):
+    # stack[CG][CG] = -240, stack[GC][GC] = -340 (rna_turner1999.par '# stack')
+    stack = blob[3:3 + 64].reshape(8, 8)
+    assert stack[1, 1] == -240 and stack[2, 2] == -340 and stack[1, 2] == -330
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from desirna_amd import engine
+    hdr = open(os.path.join(ROOT, "include", "desirna_amd.h")).read()
+    declared = set(re.findall(r"\b(drna_[a-z_]+)\s*\(", hdr))
+    assert declared == set(engine.EXPORTS)
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_simscore_mirror_matches_oracle_and_goldens(oracle, traj_golden, example_inputs):
+    from desirna_amd.sim_score import SimScore
+    for r in traj_golden[::7]:
+        tgt = example_inputs[r["run"]]["sec_struct"][0].replace("&", "Ee")
+        q = r["mfe_ss"].replace("&", "Ee")
+        s = SimScore(tgt, q)
+        s.find_basepairs()
+        s.cofusion_matrix()
+        (mcc, rec, prec), conf = oracle.simscore(tgt, q)
+        assert s.conf_mat == conf
+        assert (s.mcc(), s.recall(), s.precision()) == (mcc, rec, prec)
+        assert 1 - s.mcc() == float(r["one_minus_mcc"])
+
+
+def test_simscore_all_unpaired_special_case():
+    from desirna_amd.sim_score import SimScore
+    s = SimScore("....", "....")
+    s.find_basepairs()
+    s.cofusion_matrix()
+    assert s.mcc() == 1.0 and s.recall() == 0.0 and s.precision() == 0.0
+
+
+def test_parse_scoring_functions_first_term_quirk():
+    from desirna_amd.energy_scores import parse_scoring_functions
+    assert parse_scoring_functions("Ed-Epf:0.9,1-MCC:0.05,Edef:0.01") == [("Ed-Epf", 0.9)]
+    assert parse_scoring_functions("Ed-Epf:0.9,1-MCC:0.05", first_term_only=False) == [("Ed-Epf", 0.9), ("1-MCC", 0.05)]
+    with pytest.raises(ValueError):
+        parse_scoring_functions("Ed-Epf")
+
+
+def test_engine_fails_loudly_without_library(tmp_path):
+    from desirna_amd import engine
+    with pytest.raises(FileNotFoundError):
+        engine.load_library(str(tmp_path / "nope.so"))

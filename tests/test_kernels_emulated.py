@@ -1,0 +1,75 @@
+"""CPU-only logic check of the UNMODIFIED HIP kernel sources: tests/emu/ compiles desirna_amd/csrc/*.hpp
+against a stand-in for the few HIP constructs they use (threads = OS threads, real barriers) and the
+results are compared with the oracle.  This is not the product path and proves nothing about the GPU
+build -- the -m gpu tests do that through the C ABI -- it only lets kernel logic be debugged here."""
+import numpy as np
+import pytest
+
+from tests.emu.emu import Emu
+
+
+@pytest.fixture(scope="module")
+def emu(blob):
+    return Emu(blob)
+
+
+def _rand(rng, L, alphabet="ACGU"):
+    return "".join(rng.choice(list(alphabet), L))
+
+
+@pytest.mark.parametrize("L,nt", [(5, 64), (9, 64), (36, 128), (70, 128), (97, 256)])
+def test_mfe_pf_random(emu, oracle, L, nt):
+    rng = np.random.default_rng(100 + L)
+    seqs = [_rand(rng, L) for _ in range(3)] + [_rand(rng, L, "GC"), _rand(rng, L, "GGCCAU")]
+    E, ss, st = emu.mfe(seqs, nt=nt)
+    Ep, stp = emu.pf(seqs, nt=nt)
+    assert not st.any() and not stp.any()
+    for k, s in enumerate(seqs):
+        oss, oe = oracle.mfe(s)
+        assert (ss[k], int(E[k])) == (oss, oe), s
+        assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
+
+
+def test_mfe_tables_match_oracle(emu, oracle):
+    rng = np.random.default_rng(7)
+    s = _rand(rng, 60)
+    E, ss, st, Wc, F = emu.mfe([s], nt=128, dump=True)
+    c, f, f5 = oracle.mfe_tables(s)
+    n, INF_DEV = len(s), 1 << 22
+    for d in range(4, n):
+        for i in range(1, n - d + 1):
+            cc = Wc[d, i] >> 8
+            assert (c[i, i + d] if c[i, i + d] < 10000000 else INF_DEV) == cc
+            assert (f[i, i + d] if f[i, i + d] < 10000000 else INF_DEV) == F[d, i]
+
+
+def test_pk_rounds(emu, oracle, traj_golden):
+    rows = [r for r in traj_golden if r["run"] == "Pseudoknot_design_input" and "[" in r["mfe_ss"]][:6]
+    seqs = [r["sequence"] for r in rows]
+    E, ss, st = emu.mfe(seqs, pk_rounds=3, nt=128)
+    assert not st.any()
+    for r, got in zip(rows, ss):
+        assert got == r["mfe_ss"]
+
+
+def test_eval_kernel(emu, oracle, traj_golden, example_inputs):
+    rows = [r for r in traj_golden if r["run"] == "Alternative_structures_design_input"][:12]
+    inp = example_inputs["Alternative_structures_design_input"]
+    targets = [inp["sec_struct"][0]] + inp["alt_sec_struct"]
+    seqs = [r["sequence"] for r in rows]
+    Ed = emu.eval(seqs, targets)
+    for k, s in enumerate(seqs):
+        for t, tg in enumerate(targets):
+            assert Ed[k, t] == oracle.eval_structure(s, tg)
+    # long loops (> MAXLOOP) and a multiloop
+    s = "G" + "A" * 40 + "GGGAAACCC" + "A" * 35 + "GGGAAACCC" + "A" * 3 + "C"
+    tg = "(" + "." * 40 + "(((...)))" + "." * 35 + "(((...)))" + "." * 3 + ")"
+    s2 = "GGG" + "A" * 45 + "CCC" + "AAAA"
+    tg2 = "(((" + "." * 45 + ")))" + "...."
+    assert emu.eval([s], [tg])[0, 0] == oracle.eval_structure(s, tg)
+    assert emu.eval([s2], [tg2])[0, 0] == oracle.eval_structure(s2, tg2)
+
+
+def test_bad_character_flag(emu):
+    E, ss, st = emu.mfe(["GGGAAANCCC"], nt=64)
+    assert st[0] == 1
