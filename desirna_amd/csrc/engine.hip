@@ -15,6 +15,7 @@
 #include "../../include/desirna_amd.h"
 #include "eval_structure.hpp"
 #include "fold_mfe.hpp"
+#include "fold_mfe_lds.hpp"
 #include "fold_pf.hpp"
 #include "tables.hpp"
 
@@ -24,6 +25,7 @@ static std::string g_create_error;
 
 struct drna_engine {
   int device = 0, max_R = 0, max_L = 0, nt = 1024, cus = 0;
+  bool lds_path = true;   // LDS-resident kernels when n fits (DRNA_PATH=global forces the general path)
   HostTables H;
   MfeTables* d_mfeT = nullptr;
   PfTables* d_pfT = nullptr;
@@ -83,6 +85,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
     int v = atoi(s);
     if (v == 256 || v == 512 || v == 1024) e->nt = v;
   }
+  if (const char* s = getenv("DRNA_PATH")) e->lds_path = std::string(s) != "global";
   HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -217,7 +220,9 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
     a.Emfe = d_Emfe; a.ss = d_mfe_ss; a.status = e->d_status;
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
-    if (e->nt == 256) launch_mfe<256>(a, R, e->s_mfe);
+    if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
+      hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_mfe, a);
+    else if (e->nt == 256) launch_mfe<256>(a, R, e->s_mfe);
     else if (e->nt == 512) launch_mfe<512>(a, R, e->s_mfe);
     else launch_mfe<1024>(a, R, e->s_mfe);
     HIP_TRY(hipGetLastError());
@@ -310,3 +315,12 @@ extern "C" int drna_info(const drna_engine* e, int64_t out[6]) {
   out[0] = e->device; out[1] = e->max_R; out[2] = e->max_L; out[3] = e->nt; out[4] = e->cus; out[5] = (int64_t)e->ws_bytes;
   return DRNA_OK;
 }
+
+#ifdef DRNA_STAMPS
+// diagnostic build only: copy `count` int32 of the MFE workspace starting at int32 offset `off`
+extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, int32_t* out) {
+  if (!e || !out) return DRNA_ERR_ARG;
+  HIP_TRY(hipMemcpy(out, e->d_ws_mfe + off, (size_t)count * 4, hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
+#endif

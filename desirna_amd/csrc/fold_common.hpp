@@ -38,6 +38,17 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: global stores stay in flight across it (a plain
+// __syncthreads() also drains vmcnt, which puts HBM/L2 store latency on the per-diagonal critical path).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// value of lane `l` (wave-uniform index) as a scalar: small tables live one entry per lane
+__device__ __forceinline__ int lane_table(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 // lowest set lane of a ballot, or -1
 __device__ __forceinline__ int first_lane(unsigned long long m) { return m ? (__ffsll((long long)m) - 1) : -1; }
 

@@ -35,29 +35,34 @@ struct MfeArgs {
   int32_t* status;             // R
 };
 
-struct MfeSmem {
+template <int NLEN>
+struct MfeSmemCore {
   int stack[64];
   int mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128];
   int int11[1024];
   int d5[32], d3[32];
+  int f5[NLEN + 2];
+  short sec_i[NLEN + 2], sec_j[NLEN + 2];
+  unsigned char sec_ml[NLEN + 2];
+  unsigned char S[NLEN + 4];    // nucleotide codes, S[0] = S[n], S[n+1] = S[1]
+  unsigned char Sp[NLEN + 4];   // pairing codes (4 = hard-constrained unpaired)
+  char ssw[NLEN + 4];           // structure of the current round
+  char sspk[NLEN + 4];          // accumulated (pk-annotated) structure
+  int flag;
+};
+
+// general path: every DP table in HBM/L2, any n up to MAXN
+struct MfeSmem : MfeSmemCore<MAXN> {
   int partI[PART_ITEMS * WAVE];
   int partK[PART_ITEMS * WAVE];
-  int f5[MAXN + 2];
-  short sec_i[MAXN + 2], sec_j[MAXN + 2];
-  unsigned char sec_ml[MAXN + 2];
-  unsigned char S[MAXN + 4];    // nucleotide codes, S[0] = S[n], S[n+1] = S[1]
-  unsigned char Sp[MAXN + 4];   // pairing codes (4 = hard-constrained unpaired)
-  char ssw[MAXN + 4];           // structure of the current round
-  char sspk[MAXN + 4];          // accumulated (pk-annotated) structure
-  int flag;
 };
 
 // ---- loop energies on the device (per-lane arguments; used by finalize and traceback)
 
-__device__ __forceinline__ int mfe_hairpin(const MfeSmem& sm, const MfeArgs& A, int i, int j, int t) {
-  const MfeTables& T = *A.T;
+// ViennaRNA E_Hairpin for the pair (i,j) of type t; e = size term hairpin[u] (log-extrapolated beyond 30)
+template <class SM>
+__device__ __forceinline__ int mfe_hairpin_e(const SM& sm, const MfeTables& T, int e, int i, int j, int t) {
   const int u = j - i - 1;
-  const int e = A.hp_len[u];
   const int tau = t > 2 ? T.TermAU : 0;
   if (u == 3) {
     if (T.n_tri) {
@@ -81,9 +86,14 @@ __device__ __forceinline__ int mfe_hairpin(const MfeSmem& sm, const MfeArgs& A, 
   }
   return e + sm.mmH[t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1]];
 }
+template <class SM>
+__device__ __forceinline__ int mfe_hairpin(const SM& sm, const MfeArgs& A, int i, int j, int t) {
+  return mfe_hairpin_e(sm, *A.T, A.hp_len[j - i - 1], i, j, t);
+}
 
 // ViennaRNA E_IntLoop with the inner pair given by its packed info byte; arbitrary per-lane (u1,u2)
-__device__ __forceinline__ int mfe_intloop(const MfeSmem& sm, const MfeTables& T, int u1, int u2, int t,
+template <class SM>
+__device__ __forceinline__ int mfe_intloop(const SM& sm, const MfeTables& T, int u1, int u2, int t,
                                            int si1, int sj1, int info) {
   const int t2 = info >> 4, sq1 = (info >> 2) & 3, sp1 = info & 3;
   const int nl = u1 > u2 ? u1 : u2, ns = u1 > u2 ? u2 : u1;
@@ -109,7 +119,8 @@ __device__ __forceinline__ int mfe_intloop(const MfeSmem& sm, const MfeTables& T
   return e + sm.mmI[t * 16 + si1 * 4 + sj1] + sm.mmI[info];
 }
 
-__device__ __forceinline__ int mfe_extstem(const MfeSmem& sm, int t, int i, int j, int n) {
+template <class SM>
+__device__ __forceinline__ int mfe_extstem(const SM& sm, int t, int i, int j, int n) {
   // E_ExtLoop(type, i>1 ? S[i-1] : -1, j<n ? S[j+1] : -1), dangles = 2
   int e;
   if (i > 1 && j < n) e = sm.mmExt[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]];
@@ -259,8 +270,16 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
 
 // ---- traceback by wave 0 (wave-uniform control flow, lanes scan candidates in ViennaRNA's order)
 
-__device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
-                                     const int32_t* __restrict__ FML, const int32_t* __restrict__ EXT) {
+// fML accessor of the general path: diagonal-major table in global memory
+struct FmlGlobal {
+  const int32_t* p;
+  int ld;
+  __device__ __forceinline__ int operator()(int d, int i) const { return p[d * ld + i]; }
+};
+
+template <class SM, class FMLACC>
+__device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
+                                     const FMLACC FML, const int32_t* __restrict__ EXT) {
   const MfeTables& T = *A.T;
   const Plan& P = *A.plan;
   const int n = A.L, ld = A.ld, lane = lane_id();
@@ -308,7 +327,7 @@ __device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_
         const int jx = j - lane;            // lane tests position jx
         bool stop = true;
         if (jx > i) {
-          const int a = FML[(jx - i) * ld + i], bq = (jx - 1 - i) >= 0 ? FML[(jx - 1 - i) * ld + i] : INF_DEV;
+          const int a = FML(jx - i, i), bq = (jx - 1 - i) >= 0 ? FML(jx - 1 - i, i) : INF_DEV;
           stop = !(a == bq + T.MLbase);
         }
         const int fl = first_lane(__ballot(stop));
@@ -319,7 +338,7 @@ __device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_
         const int ix = i + lane;
         bool stop = true;
         if (ix < j) {
-          const int a = FML[(j - ix) * ld + ix], bq = FML[(j - ix - 1) * ld + ix + 1];
+          const int a = FML(j - ix, ix), bq = FML(j - ix - 1, ix + 1);
           stop = !(a == bq + T.MLbase);
         }
         const int fl = first_lane(__ballot(stop));
@@ -328,7 +347,7 @@ __device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_
       }
       if (j < i + TURN + 1) { ok = false; break; }
       const int d = j - i;
-      const int fij = FML[d * ld + i];
+      const int fij = FML(d, i);
       const int w = Wc[d * ld + i];
       const int cij = w >> 8;
       const int t = pair_type(sm.Sp[i], sm.Sp[j]);
@@ -340,7 +359,7 @@ __device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_
         for (int base = i + TURN + 1; base <= j - TURN - 2 && u < 0; base += WAVE) {
           const int x = base + lane;
           bool hit = false;
-          if (x <= j - TURN - 2) hit = fij == FML[(x - i) * ld + i] + FML[(j - x - 1) * ld + x + 1];
+          if (x <= j - TURN - 2) hit = fij == FML(x - i, i) + FML(j - x - 1, x + 1);
           const int fl = first_lane(__ballot(hit));
           if (fl >= 0) u = base + fl;
         }
@@ -387,7 +406,7 @@ __device__ inline bool mfe_traceback(MfeSmem& sm, const MfeArgs& A, const int32_
       for (int base = i + 2 + TURN; base < j - 2 - TURN && u < 0; base += WAVE) {
         const int x = base + lane;
         bool hit = false;
-        if (x < j - 2 - TURN) hit = e == FML[(x - i - 1) * ld + i + 1] + FML[(j - 1 - x - 1) * ld + x + 1];
+        if (x < j - 2 - TURN) hit = e == FML(x - i - 1, i + 1) + FML(j - 1 - x - 1, x + 1);
         const int fl = first_lane(__ballot(hit));
         if (fl >= 0) u = base + fl;
       }
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
     for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
     mfe_fill<NT>(sm, A, Wc, CI, FML, DML, EXT);     // ends with a barrier
     if (wave_id() == 0) {
-      const bool ok = mfe_traceback(sm, A, Wc, FML, EXT);
+      const bool ok = mfe_traceback(sm, A, Wc, FmlGlobal{FML, ld}, EXT);
       if (lane_id() == 0) {
         if (round == 0) A.Emfe[r] = sm.f5[n];
         sm.flag = ok ? 0 : 1;

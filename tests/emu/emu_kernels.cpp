@@ -8,6 +8,7 @@ emu_group* emu_g = nullptr;
 
 #include "../../desirna_amd/csrc/eval_structure.hpp"
 #include "../../desirna_amd/csrc/fold_mfe.hpp"
+#include "../../desirna_amd/csrc/fold_mfe_lds.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 
 using namespace drna;
@@ -43,9 +44,11 @@ int emu_mfe(const int32_t* blob, int n_int32, int R, int L, const char* seqs, in
     auto fn = [&]() {
       if (nt == 64) mfe_kernel<64>(a);
       else if (nt == 128) mfe_kernel<128>(a);
-      else mfe_kernel<256>(a);
+      else if (nt == 256) mfe_kernel<256>(a);
+      else if (nt == -256) mfe_lds_kernel<256>(a);     // LDS-resident path (needs n <= 64 at 4 waves)
+      else mfe_lds_kernel<1024>(a);                    // nt == -1024
     };
-    emu_launch(r, nt, fn);
+    emu_launch(r, nt < 0 ? -nt : nt, fn);
   }
   if (dumpWc) std::memcpy(dumpWc, ws.data(), (size_t)ld * ld * 4);
   if (dumpFML) std::memcpy(dumpFML, ws.data() + (size_t)2 * ld * ld, (size_t)ld * ld * 4);

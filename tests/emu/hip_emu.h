@@ -67,6 +67,14 @@ static inline unsigned long long __ballot(bool p) {
 }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_exchange(v, lane); }
+static inline void __builtin_amdgcn_s_barrier() { pthread_barrier_wait(&emu_g->bar); }
+#define __builtin_amdgcn_fence(...) ((void)0)
+static inline int atomicMin(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
 using std::min;
 using std::max;
 
