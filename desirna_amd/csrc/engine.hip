@@ -17,6 +17,7 @@
 #include "fold_mfe.hpp"
 #include "fold_mfe_lds.hpp"
 #include "fold_pf.hpp"
+#include "fold_pf_lds.hpp"
 #include "tables.hpp"
 
 using namespace drna;
@@ -235,7 +236,9 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
+    if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
+    else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
     else launch_pf<1024>(a, R, e->s_pf);
     HIP_TRY(hipGetLastError());

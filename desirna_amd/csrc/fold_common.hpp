@@ -10,6 +10,10 @@ constexpr int WAVE = 64;
 constexpr int MAXN = 2048;        // static LDS sizing of the per-sequence arrays
 constexpr int PART_ITEMS = 32;    // (cell-block, chunk) work items per diagonal held in LDS
 
+// tower entries (generic interior loops carried per nested-cell tower): residues of the inner diagonal
+constexpr int GRES = 28;          // 27 live entries + 1 spare
+enum : int { TW_LIVE = 0, TW_BIRTH = 1, TW_KILL = 2, TW_DEAD = 3 };   // flag in the low bits of a tower-table word
+
 // kernel status codes (per sequence)
 enum : int { ST_OK = 0, ST_BAD_CHAR = 1, ST_TRACEBACK = 2, ST_PF_RANGE = 3 };
 
@@ -48,6 +52,24 @@ __device__ __forceinline__ void lds_barrier() {
 
 // value of lane `l` (wave-uniform index) as a scalar: small tables live one entry per lane
 __device__ __forceinline__ int lane_table(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// ---- DPP wave reductions (no LDS traffic, fixed order => bit-reproducible)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
+// inclusive scan inside each row of 16 lanes, then row totals chained: lane 63 ends with the wave total
+__device__ __forceinline__ double wave_total_f64_lane63(double v) {
+  v = dpp_add_f64<0x111, 0xF>(v);   // row_shr:1
+  v = dpp_add_f64<0x112, 0xF>(v);   // row_shr:2
+  v = dpp_add_f64<0x114, 0xF>(v);   // row_shr:4
+  v = dpp_add_f64<0x118, 0xF>(v);   // row_shr:8
+  v = dpp_add_f64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add_f64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
 
 // lowest set lane of a ballot, or -1
 __device__ __forceinline__ int first_lane(unsigned long long m) { return m ? (__ffsll((long long)m) - 1) : -1; }

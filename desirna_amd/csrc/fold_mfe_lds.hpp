@@ -23,7 +23,6 @@ namespace drna {
 
 constexpr int MFE_FAST_NMAX = 200;
 constexpr int GSLOTS = 10;         // register-resident running minima per lane and parity (28 residues over >= 3 waves)
-constexpr int GRES = 28;           // residues of d' (27 live entries + 1 spare)
 
 template <int NT>
 struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
@@ -31,6 +30,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   static constexpr int RS = MFE_FAST_NMAX + 2;                                   // ring row pitch
   static constexpr int TRI = (MFE_FAST_NMAX - 4) * (MFE_FAST_NMAX - 3) / 2;      // rows 4..n-1
   static constexpr int NSLOT = 4 * WAVE;                                         // tower slots (n <= 256)
+  static constexpr int NL = MFE_FAST_NMAX + 8;
   int fml[TRI + 8];
   int wring[32 * RS];            // (c + TermAU(inner type)) * 256 + info   of the last 32 diagonals
   int ciring[32 * RS];           // c + mismatchI(inner side)               of the last 32 diagonals
@@ -40,6 +40,11 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int accG[2][NSLOT], accI[2][NSLOT], accK[2][NSLOT];   // per-tower minima, double-buffered by diagonal parity (ds_min)
   // tables with the inner pair's terminal-AU term taken out (it is folded into wring)
   int stackp[64], int11p[1024], mm1np[128], mm23p[128];
+  // per-diagonal tables prepared one step ahead by the finalize waves (double-buffered by diagonal parity)
+  int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
+  int pcnt[2];
+  int split_off[2][NL][2];       // byte offsets of the two operand rows of split point tt
+  int tower_tab[2][32][4];       // per residue: offA | flag, offB, asymmetry term, interior size term
 };
 
 // compact triangle: row d (4 <= d <= n-1) holds cells i = 1..n-d
@@ -54,38 +59,8 @@ struct FmlLds {
   }
 };
 
-// one diagonal step of the register-resident generic-interior minima of a tower; returns the generic
-// candidate (without the outer mismatch term) for the cell at column i on diagonal d.
-// xs[r]: (d - 6 - residue) mod 28 of slot r, maintained incrementally by the caller (no division).
-// v_int / v_asym: lane tables (lane s -> interior[s], lane a -> min(max_ninio, a * ninio)).
-template <int NT>
-__device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G)[GSLOTS], const int (&xs)[GSLOTS], int d,
-                                              int i, int v_int, int v_asym) {
-  constexpr int RS = MfeFastSmem<NT>::RS;
-  int acc = INF_DEV;
-#pragma unroll
-  for (int r = 0; r < GSLOTS; r++) {
-    const int x = xs[r];
-    if (x > 26) continue;                 // unused slot, or the one residue with no live entry on this diagonal
-    const int s = x + 4, dp = d - 6 - x;  // loop size and inner diagonal of this entry
-    if (dp <= TURN) { G[r] = INF_DEV; continue; }
-    const int* row = sm.ciring + (dp & 31) * RS;
-    const int as = lane_table(v_asym, s - 4);
-    if (s == 4) {
-      G[r] = row[i + 3];
-    } else if (s == 5) {
-      G[r] = min(row[i + 3], row[i + 4]) + as;
-    } else {
-      const int a = row[i + 3], b = row[i + s - 1];
-      G[r] = min(G[r], min(a, b) + as);
-      acc = min(acc, G[r] + lane_table(v_int, s));
-    }
-  }
-  return acc;
-}
-
 // Diagnostic build only (-DDRNA_STAMPS): per-wave cycle totals of each phase of block 0, written to
-// the tail of its workspace (never read by the kernel).
+// an unused part of its workspace (never read by the kernel).
 #ifdef DRNA_STAMPS
 #define STAMP(k) do { long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
 #else
@@ -105,115 +80,80 @@ __device__ __forceinline__ void mfe_f5_column(MfeFastSmem<NT>& sm, const int32_t
   sm.f5[j] = prev < m ? prev : m;
 }
 
-// ---- sweep of one diagonal by one sweep wave over NBLK live 64-tower blocks (branch-free over blocks)
-struct SweepCtx {
-  int d, par, tb_lo, aw, NA, ncand;
-  int v_cand, v_candL;      // lane k -> k-th enumerated loop shape of this wave: u1 | u2 << 8 | kind << 16, size term
-  int v_ro[4];              // lane l of v_ro[q] -> offset of fml row 64 q + l
-  int TermAU, e_bulge1, e_int23;
-};
-
-__device__ __forceinline__ int row_offset(const SweepCtx& X, int r) {
-  return r < 64 ? lane_table(X.v_ro[0], r) : r < 128 ? lane_table(X.v_ro[1], r - 64)
-       : r < 192 ? lane_table(X.v_ro[2], r - 128) : lane_table(X.v_ro[3], r - 192);
-}
-
-template <int NT, int NBLK>
-__device__ __forceinline__ void mfe_sweep_blocks(MfeFastSmem<NT>& sm, const MfeTables& T, const SweepCtx& X, int n, int sh,
-                                                 int off0, int lane) {
+// Per-diagonal tables for diagonal d (written by the finalize waves one step ahead, so the sweep waves
+// spend no scalar instructions on offsets): split point tt -> byte offsets of fML[i,i+tt] and
+// fML[i+tt+1,j] relative to column i; residue rho of an inner diagonal -> ring offsets and size terms
+// of the tower entry that lives there on diagonal d.
+template <int NT>
+__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, const MfeTables& T, int d, int n, int tid,
+                                                   int ninio, int max_ninio) {
   constexpr int RS = MfeFastSmem<NT>::RS;
-  const int d = X.d, ncell = n - d, INF = INF_DEV, HALF = INF_DEV / 2;
-  int ci[NBLK], cx[NBLK], acc[NBLK];
-  bool any_pair = false;
-#pragma unroll
-  for (int b = 0; b < NBLK; b++) {
-    int i = (X.tb_lo + b) * WAVE + lane + 1 - sh - off0;
-    const bool act = i >= 1 && i <= ncell;
-    i = i < 1 ? 1 : (i > ncell ? ncell : i);
-    const int t = act ? pair_type(sm.Sp[i], sm.Sp[i + d]) : 0;
-    ci[b] = i;
-    cx[b] = t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1];      // ij index; t == 0 <=> cx < 16
-    acc[b] = INF;
-    any_pair |= __ballot(t != 0) != 0ull;
+  const int par = d & 1;
+  if (tid >= TURN + 1 && tid <= d - TURN - 2) {
+    sm.split_off[par][tid][0] = (sm.rowoff[tid] - 1) * 4;
+    sm.split_off[par][tid][1] = (sm.rowoff[d - tid - 1] + tid) * 4;
   }
-  // ---- enumerated loops (kinds: 0 fixed small shape, 1 bulge, 2 1xn).  Loads of all blocks are issued
-  // before any is used: the LDS round trip is paid once per candidate, not once per block.
-  if (any_pair) {
-    int tq[NBLK], m1[NBLK];
-#pragma unroll
-    for (int b = 0; b < NBLK; b++) { tq[b] = (cx[b] >> 4) > 2 ? X.TermAU : 0; m1[b] = sm.mm1n[cx[b]]; }
-    for (int k = 0; k < X.ncand; k++) {
-      const int cd = lane_table(X.v_cand, k);
-      const int u1 = cd & 255, u2 = (cd >> 8) & 255, kind = cd >> 16;
-      const int dp = d - 2 - u1 - u2;
-      if (dp <= TURN) continue;
-      const int L = lane_table(X.v_candL, k);
-      const int* row = sm.wring + (dp & 31) * RS + 1 + u1;
-      int w[NBLK];
-#pragma unroll
-      for (int b = 0; b < NBLK; b++) w[b] = row[ci[b]];
-      if (kind == 1) {
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) acc[b] = min(acc[b], (w[b] >> 8) + L + tq[b]);
-      } else if (kind == 2) {
-        int m[NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) m[b] = sm.mm1np[w[b] & 127];
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) acc[b] = min(acc[b], (w[b] >> 8) + L + m[b] + m1[b]);
-      } else {
-        const int shape = L;   // 0..8: (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-          const int cpq = w[b] >> 8, info = w[b] & 127, t2 = info >> 4, t = cx[b] >> 4;
-          const int si1 = (cx[b] >> 2) & 3, sj1 = cx[b] & 3;
-          int e;
-          switch (shape) {
-            case 0: e = sm.stackp[t * 8 + t2]; break;
-            case 1: case 2: e = X.e_bulge1 + sm.stackp[t * 8 + t2]; break;
-            case 3: e = sm.int11p[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
-            case 4: e = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? X.TermAU : 0); break;
-            case 5: e = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)] - (t2 > 2 ? X.TermAU : 0); break;
-            case 6: e = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? X.TermAU : 0); break;
-            default: e = X.e_int23 + sm.mm23[cx[b]] + sm.mm23p[info]; break;   // (2,3), (3,2)
-          }
-          acc[b] = min(acc[b], cpq + e);
-        }
+  if (tid < GRES) {
+    const int x = (int)((unsigned)(d + 50 - tid) % (unsigned)GRES);     // (d - 6 - rho) mod 28
+    int w0 = TW_DEAD, w1 = 0, w2 = 0, w3 = INF_DEV;
+    if (x <= 26) {
+      const int s = x + 4, dp = d - 6 - x;
+      if (dp <= TURN) w0 = TW_KILL;
+      else {
+        const int base = (dp & 31) * RS * 4;
+        w0 = (base + 3 * 4) | (s <= 5 ? TW_BIRTH : TW_LIVE);
+        w1 = base + (s - 1) * 4;
+        w2 = min(max_ninio, (s - 4) * ninio);
+        w3 = s >= 6 ? T.interior[s] : INF_DEV;
       }
     }
-#pragma unroll
-    for (int b = 0; b < NBLK; b++)
-      if (acc[b] < HALF) atomicMin(&sm.accI[X.par][(X.tb_lo + b) * WAVE + lane], acc[b]);
+    sm.tower_tab[par][tid][0] = w0; sm.tower_tab[par][tid][1] = w1;
+    sm.tower_tab[par][tid][2] = w2; sm.tower_tab[par][tid][3] = w3;
   }
-  // ---- multiloop splits fML[i,u] + fML[u+1,j], u = i + tt, tt = 4 + aw mod NA
+}
+
+// one diagonal step of the register-resident generic-interior minima of a tower (branch-free, table-driven);
+// returns the generic candidate (without the outer mismatch term) for the cell at column i
+template <int NT>
+__device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G)[GSLOTS], int par, int i4, int g, int NG) {
+  const char* ring = reinterpret_cast<const char*>(sm.ciring);
+  int acc = INF_DEV;
 #pragma unroll
-  for (int b = 0; b < NBLK; b++) acc[b] = INF;
-  for (int tt = TURN + 1 + X.aw; tt <= d - TURN - 2; tt += X.NA) {
-    const int* ra = sm.fml + row_offset(X, tt) - 1;
-    const int* rb = sm.fml + row_offset(X, d - tt - 1) + tt;
-    int fa[NBLK], fb[NBLK];
-#pragma unroll
-    for (int b = 0; b < NBLK; b++) { fa[b] = ra[ci[b]]; fb[b] = rb[ci[b]]; }
-#pragma unroll
-    for (int b = 0; b < NBLK; b++) acc[b] = min(acc[b], fa[b] + fb[b]);
+  for (int r = 0; r < GSLOTS; r++) {
+    const int rho = r * NG + g;
+    if (rho >= GRES) continue;
+    const int* e = sm.tower_tab[par][rho];
+    const int w0 = e[0], w1 = e[1], w2 = e[2], w3 = e[3];
+    const int fl = w0 & 3;
+    const int a = *reinterpret_cast<const int*>(ring + (w0 & ~3) + i4);
+    const int b = *reinterpret_cast<const int*>(ring + w1 + i4);
+    const int v = min(a, b) + w2;
+    int gn = min(fl == TW_BIRTH ? INF_DEV : G[r], v);
+    gn = fl == TW_KILL ? INF_DEV : gn;
+    G[r] = fl == TW_DEAD ? G[r] : gn;
+    acc = min(acc, G[r] + w3);
   }
-#pragma unroll
-  for (int b = 0; b < NBLK; b++)
-    if (acc[b] < HALF) atomicMin(&sm.accK[X.par][(X.tb_lo + b) * WAVE + lane], acc[b]);
+  return acc;
 }
 
 // Structure of one diagonal step k (ONE workgroup barrier per diagonal):
 //   * waves 0..NB-1 ("finalize waves", one lane per tower slot) turn the minima gathered for diagonal
-//     k-1 into c / fML / ring rows, stream c to HBM and advance f5;
-//   * waves NB..15 ("sweep waves") gather the candidate minima of diagonal k -- tower step, enumerated
-//     small loops, multiloop splits.  None of those reads anything diagonal k-1 produces (interior loops
-//     look at diagonals <= k-2, splits at diagonals <= k-5), so the two halves run concurrently.
-// The scalar unit is shared by all 16 waves, so wave-uniform bookkeeping is kept off the inner loops:
-// no division, no per-term offset arithmetic, per-wave candidate lists and row offsets held one entry
-// per lane and fetched with v_readlane; a sweep wave takes the candidates / split points congruent to
-// its index and sweeps every live 64-tower block with them; minima meet in LDS (ds_min).
+//     k-1 into c / fML / ring rows, stream c to HBM, advance f5, and prepare the offset tables and the
+//     list of pairable cells of diagonal k+1;
+//   * waves NB..15 ("sweep waves") gather the candidate minima of diagonal k.  None of that reads
+//     anything diagonal k-1 produces (interior loops look at diagonals <= k-2, splits at <= k-5), so the
+//     two halves run concurrently.  A sweep wave does, per diagonal:
+//       T  tower step of its pinned towers (generic interior loops, 2 LDS reads per live entry);
+//       E  bulges and 1xn loops of its share of the PAIRABLE cells, one cell at a time with the 112
+//          loop shapes spread over the lanes (two passes of one wave), minima into LDS by ds_min;
+//       X  one of the nine fixed small shapes (stack, 1-bulges, 1x1, 2x1, 1x2, 2x2, 2x3, 3x2) for all
+//          pairable cells, lane = compacted cell;
+//       K  multiloop splits tt = 4 + aw (mod NA) for all cells, lane = cell.
+// Uniform bookkeeping comes from LDS tables, not from scalar arithmetic: the scalar unit is shared by
+// the 16 waves and was the bottleneck of earlier versions of this kernel.
 template <int NT>
-__device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT) {
+__device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT,
+                             int32_t* __restrict__ PL) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = MfeFastSmem<NT>::RS;
   const MfeTables& T = *A.T;
@@ -221,12 +161,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int INF = INF_DEV, HALF = INF_DEV / 2;
-  // every scalar / small table the inner loops need is taken out of global memory ONCE
   const int ninio = T.ninio, max_ninio = T.max_ninio, MLbase = T.MLbase, MLclosing = T.MLclosing,
             MLintern = T.MLintern, TermAU = T.TermAU;
-  const int lt = lane <= 30 ? lane : 30;
-  const int v_int = T.interior[lt];                                          // lane s -> interior[s]
-  const int v_asym = min(max_ninio, lane * ninio);                           // lane a -> asymmetry penalty
   // tower blocks, centred on the sequence
   const int NB = (n + WAVE - 1) / WAVE;
   const int off0 = (NB * WAVE - n) / 2;
@@ -235,42 +171,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   const int NG = NA / NB;                  // sweep waves pinned to one tower block (>= 3 for n <= 256, NT = 1024)
   const int my_tb = aw >= 0 ? aw / NG : NB, my_g = aw >= 0 ? aw - my_tb * NG : 0;
   const bool pinned = aw >= 0 && my_tb < NB;
-  int GE[GSLOTS], GO[GSLOTS], xs[GSLOTS];
-#pragma unroll
-  for (int r = 0; r < GSLOTS; r++) {
-    GE[r] = INF; GO[r] = INF;
-    const int rho = r * NG + my_g;
-    xs[r] = (pinned && rho < GRES) ? (int)((unsigned)(TURN + 1 + 50 - rho) % (unsigned)GRES) : 99;   // value for d = TURN + 1
-  }
-  SweepCtx X;
-  X.aw = aw; X.NA = NA; X.TermAU = TermAU; X.e_bulge1 = T.bulge[1]; X.e_int23 = T.interior[5] + ninio;
-  {
-    // this wave's enumerated loop shapes: the 121 shapes (9 fixed small loops, (0,u) (u,0) bulges u=2..30,
-    // (1,u) (u,1) loops u=3..29) dealt round-robin over the sweep waves; lane k holds the k-th of this wave
-    const int c = aw + lane * NA;
-    int u1 = 0, u2 = 0, kind = 0, L = 0;
-    if (c < 9) {
-      u1 = (int)((0x322211100ull >> (4 * c)) & 15ull);
-      u2 = (int)((0x232121010ull >> (4 * c)) & 15ull);
-      kind = 0; L = c;
-    } else if (c < 67) {
-      if (c < 38) { u1 = 0; u2 = c - 7; } else { u1 = c - 36; u2 = 0; }
-      kind = 1; L = T.bulge[u1 + u2 <= 30 ? u1 + u2 : 30];
-    } else if (c < 121) {
-      if (c < 94) { u1 = 1; u2 = c - 64; } else { u1 = c - 91; u2 = 1; }
-      const int nl = u1 + u2 - 1;
-      kind = 2; L = T.interior[nl + 1 <= 30 ? nl + 1 : 30] + min(max_ninio, (nl - 1) * ninio);
-    }
-    X.v_cand = u1 | (u2 << 8) | (kind << 16);
-    X.v_candL = L;
-    X.ncand = aw >= 0 ? (121 - aw + NA - 1) / NA : 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = 64 * q + lane;
-      X.v_ro[q] = (r >= TURN + 1 && r < n) ? fml_off(r, n) : 0;
-    }
-  }
 
+  // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
   for (int k = tid; k <= n; k += NT) { sm.hpl[k] = A.hp_len[k]; sm.rowoff[k] = k >= TURN + 1 ? fml_off(k, n) : 0; }
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
@@ -282,15 +184,38 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     sm.mm23p[k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
   }
   for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
+  for (int d = TURN + 1 + wave; d < n; d += NW) {
+    int base = 0;
+    for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+      const int i = i0 + lane;
+      int t = 0;
+      if (i <= n - d) t = pair_type(sm.Sp[i], sm.Sp[i + d]);
+      const unsigned long long m = __ballot(t != 0);
+      if (t) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        PL[d * ld + pos] = i | ((t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1]) << 8);
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) PL[d * ld + ld - 1] = base;     // count kept in the last word of the row
+  }
+  __syncthreads();
+  // tables and pairable list of the first diagonal
+  if (aw < 0) {
+    const int d = TURN + 1;
+    if (d < n) {
+      mfe_prepare_tables<NT>(sm, T, d, n, tid, ninio, max_ninio);
+      const int cnt = PL[d * ld + ld - 1];
+      if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
+      if (tid == 0) sm.pcnt[d & 1] = cnt;
+    }
+  }
   __syncthreads();
 
 #ifdef DRNA_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
 #endif
-  // steps k = TURN+1 .. n: sweep diagonal k (k < n) while finalizing diagonal k-1 (k-1 > TURN).  The two
-  // roles run separate copies of the loop (same trip count, one barrier per trip) so that neither
-  // carries the other's registers.
   if (aw < 0) {
     // ================= finalize waves
     for (int k = TURN + 1; k <= n; k++) {
@@ -333,6 +258,13 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           sm.fml[sm.rowoff[d] + i - 1] = min(f, dec);
         }
       }
+      // tables and pairable list of diagonal k+1 (the sweep waves are reading those of diagonal k)
+      if (k + 1 < n) {
+        mfe_prepare_tables<NT>(sm, T, k + 1, n, tid, ninio, max_ninio);
+        const int cnt = PL[(k + 1) * ld + ld - 1];
+        if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
+        if (tid == 0) sm.pcnt[(k + 1) & 1] = cnt;
+      }
       // exterior column j = k-3 by wave 0: its cells (diagonals <= k-4) were stored in step <= k-3 and
       // drained by the barrier that ended that step
       if (wave == 0 && k - 3 >= TURN + 2) mfe_f5_column<NT>(sm, EXT, ld, k - 3, lane);
@@ -342,40 +274,119 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     }
   } else {
     // ================= sweep waves
+    int GE[GSLOTS], GO[GSLOTS];
+#pragma unroll
+    for (int r = 0; r < GSLOTS; r++) { GE[r] = INF; GO[r] = INF; }
+    // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
+    // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
+    const bool b_on = lane < 58, o_on = lane < 54;
+    const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
+    const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
+    const int b_L = T.bulge[b_on ? b_s : 30];
+    const int o_nl = o_s - 1;
+    const int o_L = T.interior[o_on ? o_nl + 1 : 30] + min(max_ninio, (o_nl - 1) * ninio);
+    const int e_bulge1 = T.bulge[1], e_int23 = T.interior[5] + ninio;
+    const char* wr = reinterpret_cast<const char*>(sm.wring);
+    const char* fmlb = reinterpret_cast<const char*>(sm.fml);
+
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int lo = sh + off0, hi = ncell + sh + off0 - 1;
         const int tb_lo = lo >> 6, tb_hi = hi >> 6;
-        // ---- tower step: generic interior loops, towers pinned to their waves
+        // ---- T: tower step
         if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const int accG = par ? mfe_tower_step<NT>(sm, GO, xs, d, i, v_int, v_asym)
-                               : mfe_tower_step<NT>(sm, GE, xs, d, i, v_int, v_asym);
+          const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG)
+                               : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG);
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
         }
         STAMP(0);
-        X.d = d; X.par = par; X.tb_lo = tb_lo;
-        switch (tb_hi - tb_lo) {
-          case 0: mfe_sweep_blocks<NT, 1>(sm, T, X, n, sh, off0, lane); break;
-          case 1: mfe_sweep_blocks<NT, 2>(sm, T, X, n, sh, off0, lane); break;
-          case 2: mfe_sweep_blocks<NT, 3>(sm, T, X, n, sh, off0, lane); break;
-          default: mfe_sweep_blocks<NT, 4>(sm, T, X, n, sh, off0, lane); break;
+        const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+        const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
+        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes
+        {
+          const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
+          const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
+          const int b_off = ((b_dp & 31) * RS + 1 + b_u1) * 4, o_off = ((o_dp & 31) * RS + 1 + o_u1) * 4;
+          for (int q = aw; q < pcnt; q += NA) {
+            const int pe = sm.plist[par][q];
+            const int i = pe & 255, ij = pe >> 8;
+            const int w0 = *reinterpret_cast<const int*>(wr + b_off + i * 4);
+            const int w1 = *reinterpret_cast<const int*>(wr + o_off + i * 4);
+            const int m1 = sm.mm1np[w1 & 127];
+            int e0 = (w0 >> 8) + b_L + ((ij >> 4) > 2 ? TermAU : 0);
+            int e1 = (w1 >> 8) + o_L + m1 + sm.mm1n[ij];
+            e0 = b_ok ? e0 : INF;
+            e1 = o_ok ? e1 : INF;
+            const int m = min(e0, e1);
+            if (m < HALF) atomicMin(&sm.accI[par][i + slot0], m);
+          }
         }
         STAMP(1);
+        // ---- X: the nine fixed small shapes dealt over the sweep waves, lane = compacted pairable cell
+        for (int shp = aw; shp < 9; shp += NA) {
+          const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull);
+          const int u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
+          const int dp = d - 2 - u1 - u2;
+          if (dp > TURN) {
+            const int off = ((dp & 31) * RS + 1 + u1) * 4;
+            for (int q0 = 0; q0 < pcnt; q0 += WAVE) {
+              const int q = q0 + lane;
+              const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+              const int i = pe & 255, cxv = pe >> 8;
+              const int w = *reinterpret_cast<const int*>(wr + off + i * 4);
+              const int cpq = w >> 8, info = w & 127, t2 = info >> 4, t = cxv >> 4;
+              const int si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+              int e;
+              switch (shp) {
+                case 0: e = sm.stackp[t * 8 + t2]; break;
+                case 1: case 2: e = e_bulge1 + sm.stackp[t * 8 + t2]; break;
+                case 3: e = sm.int11p[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+                case 4: e = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); break;
+                case 5: e = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)] - (t2 > 2 ? TermAU : 0); break;
+                case 6: e = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); break;
+                default: e = e_int23 + sm.mm23[cxv] + sm.mm23p[info]; break;   // (2,3), (3,2)
+              }
+              const int v = cpq + e;
+              if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
+            }
+          }
+        }
+        STAMP(2);
+        // ---- K: multiloop splits, lane = cell, this wave's split points tt = 4 + aw (mod NA)
+        for (int b = tb_lo; b <= tb_hi; b++) {
+          int i = b * WAVE + lane + 1 - sh - off0;
+          i = i < 1 ? 1 : (i > ncell ? ncell : i);
+          const int i4 = i * 4;
+          int acc0 = INF, acc1 = INF;
+          int tt = TURN + 1 + aw;
+          for (; tt + NA <= d - TURN - 2; tt += 2 * NA) {
+            const int* o0 = sm.split_off[par][tt];
+            const int* o1 = sm.split_off[par][tt + NA];
+            const int a0 = *reinterpret_cast<const int*>(fmlb + o0[0] + i4), b0 = *reinterpret_cast<const int*>(fmlb + o0[1] + i4);
+            const int a1 = *reinterpret_cast<const int*>(fmlb + o1[0] + i4), b1 = *reinterpret_cast<const int*>(fmlb + o1[1] + i4);
+            acc0 = min(acc0, a0 + b0);
+            acc1 = min(acc1, a1 + b1);
+          }
+          if (tt <= d - TURN - 2) {
+            const int* o0 = sm.split_off[par][tt];
+            acc0 = min(acc0, *reinterpret_cast<const int*>(fmlb + o0[0] + i4) + *reinterpret_cast<const int*>(fmlb + o0[1] + i4));
+          }
+          acc0 = min(acc0, acc1);
+          if (acc0 < HALF) atomicMin(&sm.accK[par][b * WAVE + lane], acc0);
+        }
+        STAMP(5);
       }
-#pragma unroll
-      for (int r = 0; r < GSLOTS; r++)
-        if (xs[r] < 99) xs[r] = xs[r] == GRES - 1 ? 0 : xs[r] + 1;
       __syncthreads();
       STAMP(3);
     }
   }
 #ifdef DRNA_STAMPS
   if (blockIdx.x == 0 && lane == 0) {
-    long long* dbg = reinterpret_cast<long long*>(Wc + 3ll * ld * ld);
+    long long* dbg = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
   }
 #endif
@@ -396,6 +407,7 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   const long long tab = (long long)ld * ld;
   int32_t* Wc = base;
   int32_t* EXT = base + 4 * tab;
+  int32_t* PL = base + 3 * tab;      // compacted pairable-cell lists, one row per diagonal
 
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
   for (int k = tid; k < 128; k += NT) {
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   int status = ST_OK;
   for (int round = 0; round <= A.pk_rounds; round++) {
     for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
-    mfe_fill_lds<NT>(sm, A, Wc, EXT);               // ends with a barrier
+    mfe_fill_lds<NT>(sm, A, Wc, EXT, PL);           // ends with a barrier
     if (wave_id() == 0) {
       const bool ok = mfe_traceback(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT);
       if (lane_id() == 0) {

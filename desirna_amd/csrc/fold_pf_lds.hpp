@@ -1,0 +1,419 @@
+// fold_pf_lds.hpp -- LDS-resident McCaskill partition function (inside) for n <= PF_FAST_NMAX: the
+// production path of the headline workload.  Same recursions and outputs as fold_pf.hpp (reference
+// utils/energy_scores.py:150 with compute_bpp = 0); design shared with
+// fold_mfe_lds.hpp:
+//   * qb is kept as a 32-diagonal LDS ring (stored as qb * expMismatchI(inner side), plus one info byte
+//     per cell), qm / qm1 go to HBM/L2 (both full triangles are needed by the multiloop sums and do not
+//     fit in LDS in fp64), D = sum_k qm qm1 of the last four diagonals and the previous diagonal of qm1
+//     and U stay in LDS;
+//   * generic interior loops by register-resident tower sums (2 LDS reads per live inner diagonal);
+//   * bulges and 1xn loops one PAIRABLE cell at a time with the 112 shapes spread over the lanes and a
+//     DPP wave sum; the nine fixed small shapes by one wave per 64 pairable cells;
+//   * multiloop sums from L2: a wave takes 16 cells x 4 interleaved split-point groups, 16 loads in
+//     flight per lane;
+//   * finalize waves (one lane per cell) run one diagonal behind the sweep waves: one barrier per
+//     diagonal.  Every partial sum has exactly one writer and is combined in a fixed order, so the
+//     result is bit-reproducible from run to run and independent of the batch composition.
+#pragma once
+#include "fold_pf.hpp"
+
+namespace drna {
+
+constexpr int PF_FAST_NMAX = 200;
+constexpr int PGSLOTS = 10;       // tower entries per pinned wave: 28 residues over 3 waves
+constexpr int PNG = 3;            // sweep waves pinned to one 64-tower block
+
+template <int NT>
+struct PfFastSmem {
+  static constexpr int NW = NT / WAVE;
+  static constexpr int RS = PF_FAST_NMAX + 2;
+  static constexpr int NSLOT = 4 * WAVE;
+  static constexpr int NL = PF_FAST_NMAX + 8;
+  double qbi[32 * RS];            // qb * expMismatchI(inner side) of the last 32 diagonals
+  double dring[4 * RS];           // D[i,j] = sum_k qm[i,k-1] qm1[k,j] of the last 4 diagonals
+  double qm1row[2][RS];           // qm1 of the previous diagonal
+  double urow[2][RS];             // U of the previous diagonal
+  double hpw[PF_FAST_NMAX + 2];   // hairpin weight by loop size (scale folded in)
+  double q5[PF_FAST_NMAX + 2];
+  double partG[2][PNG][NSLOT];    // tower sums, one slice per pinned wave
+  double partK[2][4][NSLOT];      // multiloop sums, one slice per split-point group
+  double accE[2][NSLOT], accX[2][NSLOT];
+  // Boltzmann tables
+  double stack[64], mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128], int11[1024], d5[32], d3[32];
+  double rinv[128];               // 1 / expMismatchI(info)
+  double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
+  double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
+  double r23[128];                // expMismatch23I(info) / expMismatchI(info)
+  double tw_d[2][32][3];          // per residue: asymmetry factor, size factor, weight of the second boundary term
+  int tw_i[2][32][2];             // per residue: offA | flag, offB (byte offsets into qbi)
+  int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
+  int pcnt[2];
+  unsigned char info[32 * RS];
+  unsigned char S[PF_FAST_NMAX + 4];
+  int flag;
+};
+
+// exterior column j: q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j); one wave
+template <int NT>
+__device__ __forceinline__ void pf_q5_column(PfFastSmem<NT>& sm, const double* __restrict__ QEXT, int ld, int j, int lane,
+                                             double sc1) {
+  double s = 0.0;
+  for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) s += sm.q5[i - 1] * QEXT[j * ld + i];
+  s = wave_sum_f64(s);
+  sm.q5[j] = sm.q5[j - 1] * sc1 + s;      // every lane stores the same value
+}
+
+template <int NT>
+__device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, const PfTables& T, const double* scale, int d, int tid) {
+  constexpr int RS = PfFastSmem<NT>::RS;
+  if (tid < GRES) {
+    const int par = d & 1;
+    const int x = (int)((unsigned)(d + 50 - tid) % (unsigned)GRES);     // (d - 6 - rho) mod 28
+    int w0 = TW_DEAD, w1 = 0;
+    double eas = 0.0, W = 0.0, wb = 0.0;
+    if (x <= 26) {
+      const int s = x + 4, dp = d - 6 - x;
+      if (dp <= TURN) w0 = TW_KILL;
+      else {
+        const int base = (dp & 31) * RS * 8;
+        w0 = (base + 3 * 8) | (s <= 5 ? TW_BIRTH : TW_LIVE);
+        w1 = base + (s - 1) * 8;
+        eas = T.eninio[s - 4];
+        W = s >= 6 ? T.interior[s] * scale[s + 2] : 0.0;
+        wb = s == 4 ? 0.0 : 1.0;
+      }
+    }
+    sm.tw_i[par][tid][0] = w0; sm.tw_i[par][tid][1] = w1;
+    sm.tw_d[par][tid][0] = eas; sm.tw_d[par][tid][1] = W; sm.tw_d[par][tid][2] = wb;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int par, int i8, int g) {
+  const char* ring = reinterpret_cast<const char*>(sm.qbi);
+  // loads first (tables, then ring operands), arithmetic after: two LDS round trips for all entries
+  int w0[PGSLOTS], w1[PGSLOTS];
+  double a[PGSLOTS], b[PGSLOTS];
+#pragma unroll
+  for (int r = 0; r < PGSLOTS; r++) {
+    const int rho = r * PNG + g;
+    w0[r] = rho < GRES ? sm.tw_i[par][rho][0] : TW_DEAD;
+    w1[r] = rho < GRES ? sm.tw_i[par][rho][1] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < PGSLOTS; r++) {
+    a[r] = *reinterpret_cast<const double*>(ring + (w0[r] & ~3) + i8);
+    b[r] = *reinterpret_cast<const double*>(ring + w1[r] + i8);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < PGSLOTS; r++) {
+    const int rho = r * PNG + g;
+    if (rho >= GRES) continue;
+    const double* e = sm.tw_d[par][rho];
+    const int fl = w0[r] & 3;
+    const double v = (a[r] + e[2] * b[r]) * e[0];
+    double gn = (fl == TW_BIRTH ? 0.0 : G[r]) + v;
+    gn = fl == TW_KILL ? 0.0 : gn;
+    G[r] = fl == TW_DEAD ? G[r] : gn;
+    acc += G[r] * e[1];
+  }
+  return acc;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
+  __shared__ PfFastSmem<NT> sm;
+  constexpr int NW = NT / WAVE;
+  constexpr int RS = PfFastSmem<NT>::RS;
+  const PfTables& T = *A.T;
+  const int r = blockIdx.x;
+  const int n = A.L, ld = A.ld;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+
+  double* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  double* QM = base + 2 * tab;
+  double* QM1 = base + 3 * tab;
+  int32_t* PL = reinterpret_cast<int32_t*>(base + 4 * tab);   // compacted pairable-cell lists, one row per diagonal
+  double* QEXT = base + 6 * tab;
+
+  const double eTau = T.TermAU, eMLc = T.MLclosing, eMLi = T.MLintern;
+  const double b1 = A.eMLb[1], sc1 = A.scale[1], sc2 = A.scale[2];
+
+  // ---- prologue
+  for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
+  for (int k = tid; k < 128; k += NT) {
+    sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
+    sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
+    const double inv = 1.0 / T.mmI[k];
+    sm.rinv[k] = inv;
+    sm.rbul[k] = ((k >> 4) > 2 ? eTau : 1.0) * inv;
+    sm.r1n[k] = T.mm1n[k] * inv;
+    sm.r23[k] = T.mm23[k] * inv;
+  }
+  for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
+  for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
+  for (int k = tid; k < 4 * RS; k += NT) sm.dring[k] = 0.0;
+  for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
+  for (int k = tid; k < 2 * PNG * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
+  for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
+  for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) { (&sm.accE[0][0])[k] = 0.0; (&sm.accX[0][0])[k] = 0.0; }
+  if (tid == 0) { sm.flag = 0; sm.q5[0] = 1.0; }
+  __syncthreads();
+  const char* seq = A.seqs + (long long)r * n;
+  for (int k = tid; k < n; k += NT) {
+    const int c = enc_nt(seq[k]);
+    if (c < 0) sm.flag = 1;
+    sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
+  }
+  __syncthreads();
+  if (tid == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
+  __syncthreads();
+  if (sm.flag) {
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Epf[r] = 0.0; }
+    return;
+  }
+  if (wave == 0) {                                   // q5[j] = scale^j while no pair fits (j <= TURN + 1)
+    for (int j = 1; j <= n && j <= TURN + 1; j++) sm.q5[j] = sm.q5[j - 1] * sc1;
+  }
+  // compacted list of pairable cells of every diagonal (HBM/L2)
+  for (int d = TURN + 1 + wave; d < n; d += NW) {
+    int cntb = 0;
+    for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+      const int i = i0 + lane;
+      int t = 0;
+      if (i <= n - d) t = pair_type(sm.S[i], sm.S[i + d]);
+      const unsigned long long m = __ballot(t != 0);
+      if (t) {
+        const int pos = cntb + __popcll(m & ((1ull << lane) - 1ull));
+        PL[d * ld + pos] = i | ((t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1]) << 8);
+      }
+      cntb += __popcll(m);
+    }
+    if (lane == 0) PL[d * ld + ld - 1] = cntb;
+  }
+  __syncthreads();
+
+  // tower blocks, centred on the sequence
+  const int NB = (n + WAVE - 1) / WAVE;
+  const int off0 = (NB * WAVE - n) / 2;
+  const int NA = NW - NB;                  // sweep waves
+  const int aw = wave - NB;                // index among the sweep waves (< 0: finalize wave)
+  const int my_tb = aw >= 0 ? aw / PNG : NB, my_g = aw >= 0 ? aw - my_tb * PNG : 0;
+  const bool pinned = aw >= 0 && my_tb < NB;
+
+  if (aw < 0) {
+    const int d = TURN + 1;
+    if (d < n) {
+      pf_prepare_tables<NT>(sm, T, A.scale, d, tid);
+      const int cnt = PL[d * ld + ld - 1];
+      if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
+      if (tid == 0) sm.pcnt[d & 1] = cnt;
+    }
+  }
+  __syncthreads();
+
+  if (aw < 0) {
+    // ================= finalize waves: diagonal d = k-1 at step k
+    for (int k = TURN + 1; k <= n; k++) {
+      const int d = k - 1;
+      if (d > TURN) {
+        const int ncell = n - d, sh = d >> 1, par = d & 1;
+        const int i = tid + 1 - sh - off0;
+        if (i >= 1 && i <= ncell) {
+          const double aG = (sm.partG[par][0][tid] + sm.partG[par][1][tid]) + sm.partG[par][2][tid];
+          const double aK = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
+          const double aE = sm.accE[par][tid], aX = sm.accX[par][tid];
+          sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0; sm.partG[par][2][tid] = 0.0;
+          sm.partK[par][0][tid] = 0.0; sm.partK[par][1][tid] = 0.0; sm.partK[par][2][tid] = 0.0; sm.partK[par][3][tid] = 0.0;
+          sm.accE[par][tid] = 0.0; sm.accX[par][tid] = 0.0;
+          const int j = i + d;
+          const int t = pair_type(sm.S[i], sm.S[j]);
+          const double tau = t > 2 ? eTau : 1.0;
+          double qb = 0.0;
+          int info = 0;
+          if (t) {
+            const int u = d - 1;
+            const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
+            double hp;
+            if (u == 3 || u == 4 || u == 6) {
+              // special hairpins (tri / tetra / hexa loops) go through the general routine
+              int code = 0;
+              const int len = u + 2;
+              for (int q = 0; q < len; q++) code |= sm.S[i + q] << (2 * q);
+              hp = -1.0;
+              if (u == 3) { for (int q = 0; q < T.n_tri; q++) if (T.tri_code[q] == code) hp = T.tri_w[q] * A.scale[u + 2]; if (hp < 0.0) hp = sm.hpw[u] * tau; }
+              else if (u == 4) { for (int q = 0; q < T.n_tetra; q++) if (T.tetra_code[q] == code) hp = T.tetra_w[q] * A.scale[u + 2]; }
+              else { for (int q = 0; q < T.n_hexa; q++) if (T.hexa_code[q] == code) hp = T.hexa_w[q] * A.scale[u + 2]; }
+              if (hp < 0.0) hp = sm.hpw[u] * sm.mmH[ij];
+            } else {
+              hp = sm.hpw[u] * sm.mmH[ij];
+            }
+            qb = hp + aE + aX + aG * sm.mmI[ij];
+            qb += sm.dring[((d - 2) & 3) * RS + i + 1] * eMLc * eMLi * tau *
+                  sm.mmM[rtype_of(t) * 16 + sm.S[j - 1] * 4 + sm.S[i + 1]] * sc2;
+            info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
+          }
+          sm.qbi[(d & 31) * RS + i] = qb * sm.mmI[info];
+          sm.info[(d & 31) * RS + i] = (unsigned char)info;
+          double ext = 0.0, stem = 0.0;
+          if (t) {
+            double me, mm;
+            if (i > 1 && j < n) { me = sm.mmExt[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]; mm = sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]; }
+            else if (i > 1) { me = mm = sm.d5[t * 4 + sm.S[i - 1]]; }
+            else if (j < n) { me = mm = sm.d3[t * 4 + sm.S[j + 1]]; }
+            else { me = mm = 1.0; }
+            ext = qb * tau * me;
+            stem = qb * eMLi * tau * mm;
+          }
+          QEXT[j * ld + i] = ext;
+          const int pp = (d - 1) & 1;
+          const double m1 = sm.qm1row[pp][i] * b1 + stem;
+          const double U = b1 * (sm.qm1row[pp][i + 1] + sm.urow[pp][i + 1]);
+          sm.qm1row[par][i] = m1;
+          sm.urow[par][i] = U;
+          sm.dring[(d & 3) * RS + i] = aK;
+          QM1[d * ld + i] = m1;
+          QM[d * ld + i] = m1 + aK + U;
+        }
+      }
+      if (k + 1 < n) {
+        pf_prepare_tables<NT>(sm, T, A.scale, k + 1, tid);
+        const int cnt = PL[(k + 1) * ld + ld - 1];
+        if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
+        if (tid == 0) sm.pcnt[(k + 1) & 1] = cnt;
+      }
+      // exterior column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier)
+      if (wave == 0 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
+      __syncthreads();
+    }
+  } else {
+    // ================= sweep waves: diagonal d = k at step k
+    double GE[PGSLOTS], GO[PGSLOTS];
+#pragma unroll
+    for (int q = 0; q < PGSLOTS; q++) { GE[q] = 0.0; GO[q] = 0.0; }
+    // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
+    // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
+    const bool b_on = lane < 58, o_on = lane < 54;
+    const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
+    const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
+    const double b_W = T.bulge[b_s] * A.scale[b_s + 2];
+    const int o_nl = o_s - 1;
+    const double o_W = T.interior[o_nl + 1] * T.eninio[o_nl - 1] * A.scale[o_s + 2];
+    // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
+    const double x_b1 = T.bulge[1] * A.scale[3], x_23 = T.interior[5] * T.eninio[1] * A.scale[7];
+    const double sc4 = A.scale[4], sc5 = A.scale[5], sc6 = A.scale[6];
+    const char* qr = reinterpret_cast<const char*>(sm.qbi);
+
+    for (int k = TURN + 1; k <= n; k++) {
+      if (k < n) {
+        const int d = k;
+        const int ncell = n - d, sh = d >> 1, par = d & 1;
+        const int lo = sh + off0, hi = ncell + sh + off0 - 1;
+        const int tb_lo = lo >> 6, tb_hi = hi >> 6;
+        const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
+        // ---- T: tower step
+        if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
+          int i = my_tb * WAVE + lane + 1 - sh - off0;
+          i = i < 1 ? 1 : (i > ncell ? ncell : i);
+          const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g);
+          sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
+        }
+        const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes (two cells per trip)
+        {
+          const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
+          const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
+          const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
+          for (int q = aw; q < pcnt; q += 2 * NA) {
+            const bool two = q + NA < pcnt;
+            const int pe0 = sm.plist[par][q], pe1 = sm.plist[par][two ? q + NA : q];
+            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
+            const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
+            const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
+            const int f00 = sm.info[b_off + i0], f01 = sm.info[o_off + i0];
+            const int f10 = sm.info[b_off + i1], f11 = sm.info[o_off + i1];
+            const double r00 = sm.rbul[f00], r01 = sm.r1n[f01], r10 = sm.rbul[f10], r11 = sm.r1n[f11];
+            const double m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+            double v0 = (b_ok ? w00 * r00 * b_W : 0.0) * ((ij0 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w01 * r01 * o_W : 0.0) * m0;
+            double v1 = (b_ok ? w10 * r10 * b_W : 0.0) * ((ij1 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w11 * r11 * o_W : 0.0) * m1;
+            v0 = wave_total_f64_lane63(v0);
+            v1 = wave_total_f64_lane63(v1);
+            if (lane == WAVE - 1) {
+              sm.accE[par][i0 + slot0] = v0;
+              if (two) sm.accE[par][i1 + slot0] = v1;
+            }
+          }
+        }
+        // ---- X: the nine fixed small shapes, all by one wave per 64 pairable cells (lane = compacted cell)
+        for (int ch = 0; ch * WAVE < pcnt; ch++) {
+          if (aw != NA - 1 - (ch % NA)) continue;
+          const int q = ch * WAVE + lane;
+          const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+          const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+          double w[9];
+          int f[9];
+#pragma unroll
+          for (int shp = 0; shp < 9; shp++) {
+            const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull), u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
+            const int dp = d - 2 - u1 - u2;
+            const int off = (dp & 31) * RS + 1 + u1 + i;
+            w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
+            f[shp] = dp > TURN ? sm.info[off] : 0;
+          }
+          double sum = 0.0;
+          { const int t2 = f[0] >> 4; sum += w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + t2] * sc2; }
+          { const int t2 = f[1] >> 4; sum += w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + t2] * x_b1; }
+          { const int t2 = f[2] >> 4; sum += w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + t2] * x_b1; }
+          { const int t2 = f[3] >> 4; sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1] * sc4; }
+          { const int t2 = f[4] >> 4; sum += w[4] * sm.rinv[f[4]] * T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((f[4] >> 2) & 3) * 4 + sj1] * sc5; }
+          { const int t2 = f[5] >> 4; sum += w[5] * sm.rinv[f[5]] * T.int21[(t2 * 8 + t) * 64 + ((f[5] >> 2) & 3) * 16 + si1 * 4 + (f[5] & 3)] * sc5; }
+          { const int t2 = f[6] >> 4; sum += w[6] * sm.rinv[f[6]] * T.int22[(t * 8 + t2) * 256 + si1 * 64 + (f[6] & 3) * 16 + ((f[6] >> 2) & 3) * 4 + sj1] * sc6; }
+          sum += (w[7] * sm.r23[f[7]] + w[8] * sm.r23[f[8]]) * sm.mm23[cxv] * x_23;
+          if (q < pcnt) sm.accX[par][i + slot0] = sum;
+        }
+        // ---- K: multiloop sums from L2.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
+        {
+          const int g = lane >> 4, cl = lane & 15;
+          for (int sb = aw; sb * 16 < ncell; sb += NA) {
+            int i = sb * 16 + cl + 1;
+            const bool act = i <= ncell;
+            i = act ? i : ncell;
+            double acc0 = 0.0, acc1 = 0.0;
+            int tt = TURN + 1 + g;
+            for (; tt + 12 <= d - TURN - 2; tt += 16) {
+              const double a0 = QM[tt * ld + i], c0 = QM1[(d - tt - 1) * ld + i + tt + 1];
+              const double a1 = QM[(tt + 4) * ld + i], c1 = QM1[(d - tt - 5) * ld + i + tt + 5];
+              const double a2 = QM[(tt + 8) * ld + i], c2 = QM1[(d - tt - 9) * ld + i + tt + 9];
+              const double a3 = QM[(tt + 12) * ld + i], c3 = QM1[(d - tt - 13) * ld + i + tt + 13];
+              acc0 += a0 * c0; acc1 += a1 * c1; acc0 += a2 * c2; acc1 += a3 * c3;
+            }
+            for (; tt <= d - TURN - 2; tt += 4) acc0 += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
+            if (act) sm.partK[par][g][i + slot0] = acc0 + acc1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // the remaining exterior columns, then Z
+  if (wave == 0) {
+    for (int j = max(TURN + 2, n - 2); j <= n; j++) pf_q5_column<NT>(sm, QEXT, ld, j, lane, sc1);
+    if (lane == 0) {
+      const double Z = sm.q5[n];
+      if (!(Z > 0.0) || !(Z < 1.0e300)) {
+        A.status[r] = ST_PF_RANGE;
+        A.Epf[r] = 0.0;
+      } else {
+        A.status[r] = ST_OK;
+        A.Epf[r] = (-log(Z) - (double)n * log(T.pf_scale)) * T.kT / 1000.0;
+      }
+    }
+  }
+}
+
+}  // namespace drna

@@ -10,6 +10,7 @@ emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_mfe.hpp"
 #include "../../desirna_amd/csrc/fold_mfe_lds.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
+#include "../../desirna_amd/csrc/fold_pf_lds.hpp"
 
 using namespace drna;
 
@@ -71,9 +72,11 @@ int emu_pf(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int
     auto fn = [&]() {
       if (nt == 64) pf_kernel<64>(a);
       else if (nt == 128) pf_kernel<128>(a);
-      else pf_kernel<256>(a);
+      else if (nt == 256) pf_kernel<256>(a);
+      else if (nt == -256) pf_lds_kernel<256>(a);
+      else pf_lds_kernel<1024>(a);
     };
-    emu_launch(r, nt, fn);
+    emu_launch(r, nt < 0 ? -nt : nt, fn);
   }
   delete c;
   return 0;

@@ -66,8 +66,26 @@ static inline unsigned long long __ballot(bool p) {
   return m;
 }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_exchange(v, lane); }
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  (void)bank_mask;
+  const int L = threadIdx.x & 63, r = L >> 4;
+  int from = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int nsh = ctrl - 0x110; if ((L & 15) >= nsh) from = L - nsh; }
+  else if (ctrl == 0x142) { if (r > 0) from = r * 16 - 1; }
+  else if (ctrl == 0x143) { if (r >= 2) from = 31; }
+  const int got = emu_exchange(src, from < 0 ? L : from);       // every lane takes part in the rendezvous
+  if (!((row_mask >> r) & 1)) return old;
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
+static inline int __double2loint(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return (int)(b & 0xffffffffull); }
+static inline int __double2hiint(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return (int)(b >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+  unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double v; std::memcpy(&v, &b, 8); return v;
+}
 static inline void __builtin_amdgcn_s_barrier() { pthread_barrier_wait(&emu_g->bar); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 static inline int atomicMin(int* p, int v) {
