@@ -53,6 +53,10 @@ __device__ __forceinline__ void lds_barrier() {
 // value of lane `l` (wave-uniform index) as a scalar: small tables live one entry per lane
 __device__ __forceinline__ int lane_table(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+// Keep a wave-uniform index in a VGPR (identity quad_perm DPP move).  hipcc otherwise turns a uniform-address
+// LDS read into ds_read + s_waitcnt lgkmcnt(0) + v_readfirstlane: a full LDS round trip per value, serialised.
+__device__ __forceinline__ int as_vector(int x) { return __builtin_amdgcn_update_dpp(x, x, 0xE4, 0xF, 0xF, false); }
+
 // ---- DPP wave reductions (no LDS traffic, fixed order => bit-reproducible)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {
@@ -68,6 +72,23 @@ __device__ __forceinline__ double wave_total_f64_lane63(double v) {
   v = dpp_add_f64<0x118, 0xF>(v);   // row_shr:8
   v = dpp_add_f64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
   v = dpp_add_f64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_i32(int v) {
+  // lanes without a source (row edge / masked row) see their own value: min is idempotent
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+  return o < v ? o : v;
+}
+// lane 63 ends with the wave minimum
+__device__ __forceinline__ int wave_min_i32_lane63(int v) {
+  v = dpp_min_i32<0x111, 0xF>(v);
+  v = dpp_min_i32<0x112, 0xF>(v);
+  v = dpp_min_i32<0x114, 0xF>(v);
+  v = dpp_min_i32<0x118, 0xF>(v);
+  v = dpp_min_i32<0x142, 0xA>(v);
+  v = dpp_min_i32<0x143, 0xC>(v);
   return v;
 }
 

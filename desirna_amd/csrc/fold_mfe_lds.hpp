@@ -44,7 +44,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int split_off[2][NL][2];       // byte offsets of the two operand rows of split point tt
-  int tower_tab[2][32][4];       // per residue: offA | flag, offB, asymmetry term, interior size term
+  int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
 };
 
 // compact triangle: row d (4 <= d <= n-1) holds cells i = 1..n-d
@@ -94,44 +94,52 @@ __device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, const Mf
     sm.split_off[par][tid][1] = (sm.rowoff[d - tid - 1] + tid) * 4;
   }
   if (tid < GRES) {
+    // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
+    //   G <- min(max(G, floor), min(ring[A + i], ring[B + i]) + asym);  candidate = G + size
+    // dead / not yet possible entries: asym = INF (G unchanged or INF), size = INF (no candidate)
     const int x = (int)((unsigned)(d + 50 - tid) % (unsigned)GRES);     // (d - 6 - rho) mod 28
-    int w0 = TW_DEAD, w1 = 0, w2 = 0, w3 = INF_DEV;
+    int offA = 0, offB = 0, as = INF_DEV, fl = -INF_DEV, L = INF_DEV;
     if (x <= 26) {
       const int s = x + 4, dp = d - 6 - x;
-      if (dp <= TURN) w0 = TW_KILL;
+      if (dp <= TURN) fl = INF_DEV;                                      // entry exists but has no inner pair yet: G = INF
       else {
         const int base = (dp & 31) * RS * 4;
-        w0 = (base + 3 * 4) | (s <= 5 ? TW_BIRTH : TW_LIVE);
-        w1 = base + (s - 1) * 4;
-        w2 = min(max_ninio, (s - 4) * ninio);
-        w3 = s >= 6 ? T.interior[s] : INF_DEV;
+        offA = base + 3 * 4;
+        offB = base + (s - 1) * 4;
+        as = min(max_ninio, (s - 4) * ninio);
+        fl = s <= 5 ? INF_DEV : -INF_DEV;                                // first appearance: forget the previous tenant
+        L = s >= 6 ? T.interior[s] : INF_DEV;
       }
     }
-    sm.tower_tab[par][tid][0] = w0; sm.tower_tab[par][tid][1] = w1;
-    sm.tower_tab[par][tid][2] = w2; sm.tower_tab[par][tid][3] = w3;
+    int* e = sm.tower_tab[par][tid];
+    e[0] = offA; e[1] = offB; e[2] = as; e[3] = fl; e[4] = L; e[5] = 0;
   }
 }
 
 // one diagonal step of the register-resident generic-interior minima of a tower (branch-free, table-driven);
 // returns the generic candidate (without the outer mismatch term) for the cell at column i
 template <int NT>
-__device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G)[GSLOTS], int par, int i4, int g, int NG) {
+__device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G)[GSLOTS], int par, int i4, int g, int NG, int lane) {
   const char* ring = reinterpret_cast<const char*>(sm.ciring);
+  // lane r fetches the table entry of slot r (one LDS round trip for the whole wave); the words are then
+  // broadcast with v_readlane as they are needed -- no per-slot LDS read, no scalarised loads
+  const int rr = lane * NG + g;
+  const bool on = lane < GSLOTS && rr < GRES;
+  const int* e = sm.tower_tab[par][on ? rr : 0];
+  const int eA = e[0], eB = e[1];
+  const int eas = on ? e[2] : INF_DEV, efl = on ? e[3] : -INF_DEV, eL = on ? e[4] : INF_DEV;
+  int a[GSLOTS], b[GSLOTS];
+#pragma unroll
+  for (int r = 0; r < GSLOTS; r++) {
+    a[r] = *reinterpret_cast<const int*>(ring + lane_table(eA, r) + i4);
+    b[r] = *reinterpret_cast<const int*>(ring + lane_table(eB, r) + i4);
+  }
   int acc = INF_DEV;
 #pragma unroll
   for (int r = 0; r < GSLOTS; r++) {
-    const int rho = r * NG + g;
-    if (rho >= GRES) continue;
-    const int* e = sm.tower_tab[par][rho];
-    const int w0 = e[0], w1 = e[1], w2 = e[2], w3 = e[3];
-    const int fl = w0 & 3;
-    const int a = *reinterpret_cast<const int*>(ring + (w0 & ~3) + i4);
-    const int b = *reinterpret_cast<const int*>(ring + w1 + i4);
-    const int v = min(a, b) + w2;
-    int gn = min(fl == TW_BIRTH ? INF_DEV : G[r], v);
-    gn = fl == TW_KILL ? INF_DEV : gn;
-    G[r] = fl == TW_DEAD ? G[r] : gn;
-    acc = min(acc, G[r] + w3);
+    const int v = min(a[r], b[r]) + lane_table(eas, r);
+    G[r] = min(max(G[r], lane_table(efl, r)), v);
+    acc = min(acc, G[r] + lane_table(eL, r));
   }
   return acc;
 }
@@ -174,6 +182,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
+  for (int k = tid; k < 32 * RS; k += NT) { sm.wring[k] = INF * 256; sm.ciring[k] = INF; }   // idle tower entries read row 0
   for (int k = tid; k <= n; k += NT) { sm.hpl[k] = A.hp_len[k]; sm.rowoff[k] = k >= TURN + 1 ? fml_off(k, n) : 0; }
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
@@ -223,6 +232,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
       if (d > TURN) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
+        const int dv = as_vector(d), dm1v = as_vector(d - 1);   // uniform LDS indices kept in VGPRs (outside divergent code)
         if (i >= 1 && i <= ncell) {
           const int aG = sm.accG[par][tid], aI = sm.accI[par][tid], aK = sm.accK[par][tid];
           sm.accG[par][tid] = INF; sm.accI[par][tid] = INF; sm.accK[par][tid] = INF;
@@ -232,7 +242,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           int c = INF, info = 0, cb = INF;
           if (t) {
             const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
-            c = mfe_hairpin_e(sm, T, sm.hpl[d - 1], i, j, t);
+            c = mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
             c = min(c, aI);
             c = min(c, aG + sm.mmI[ij]);
             const int dml = sm.dml[((d - 2) & 3) * RS + i + 1];
@@ -248,14 +258,15 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           EXT[j * ld + i] = c < INF ? c + tau + mfe_extstem(sm, t, i, j, n) : INF;
           int f = INF;
           if (d - 1 > TURN) {
-            const int fa = sm.fml[sm.rowoff[d - 1] + i], fb = sm.fml[sm.rowoff[d - 1] + i - 1];
+            const int ro1 = sm.rowoff[dm1v];
+            const int fa = sm.fml[ro1 + i], fb = sm.fml[ro1 + i - 1];
             if (fa < HALF) f = fa + MLbase;
             if (fb < HALF) f = min(f, fb + MLbase);
           }
           if (c < INF) f = min(f, c + MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
           const int dec = aK >= HALF ? INF : aK;
           sm.dml[(d & 3) * RS + i] = dec;
-          sm.fml[sm.rowoff[d] + i - 1] = min(f, dec);
+          sm.fml[sm.rowoff[dv] + i - 1] = min(f, dec);
         }
       }
       // tables and pairable list of diagonal k+1 (the sweep waves are reading those of diagonal k)
@@ -286,8 +297,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     const int o_nl = o_s - 1;
     const int o_L = T.interior[o_on ? o_nl + 1 : 30] + min(max_ninio, (o_nl - 1) * ninio);
     const int e_bulge1 = T.bulge[1], e_int23 = T.interior[5] + ninio;
-    const char* wr = reinterpret_cast<const char*>(sm.wring);
-    const char* fmlb = reinterpret_cast<const char*>(sm.fml);
+    // K work goes first to the waves whose tower blocks die early (outer blocks)
+    const int krank = NB == 4 ? (aw < 3 ? aw : aw >= 9 ? aw - 6 : aw + 3) : aw;
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -299,84 +310,90 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG)
-                               : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG);
+          const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG, lane)
+                               : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG, lane);
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
         }
         STAMP(0);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
         const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
-        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes
+        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes (two cells per trip)
         {
           const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
           const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-          const int b_off = ((b_dp & 31) * RS + 1 + b_u1) * 4, o_off = ((o_dp & 31) * RS + 1 + o_u1) * 4;
-          for (int q = aw; q < pcnt; q += NA) {
-            const int pe = sm.plist[par][q];
-            const int i = pe & 255, ij = pe >> 8;
-            const int w0 = *reinterpret_cast<const int*>(wr + b_off + i * 4);
-            const int w1 = *reinterpret_cast<const int*>(wr + o_off + i * 4);
-            const int m1 = sm.mm1np[w1 & 127];
-            int e0 = (w0 >> 8) + b_L + ((ij >> 4) > 2 ? TermAU : 0);
-            int e1 = (w1 >> 8) + o_L + m1 + sm.mm1n[ij];
-            e0 = b_ok ? e0 : INF;
-            e1 = o_ok ? e1 : INF;
-            const int m = min(e0, e1);
-            if (m < HALF) atomicMin(&sm.accI[par][i + slot0], m);
-          }
-        }
-        STAMP(1);
-        // ---- X: the nine fixed small shapes dealt over the sweep waves, lane = compacted pairable cell
-        for (int shp = aw; shp < 9; shp += NA) {
-          const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull);
-          const int u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
-          const int dp = d - 2 - u1 - u2;
-          if (dp > TURN) {
-            const int off = ((dp & 31) * RS + 1 + u1) * 4;
-            for (int q0 = 0; q0 < pcnt; q0 += WAVE) {
-              const int q = q0 + lane;
-              const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-              const int i = pe & 255, cxv = pe >> 8;
-              const int w = *reinterpret_cast<const int*>(wr + off + i * 4);
-              const int cpq = w >> 8, info = w & 127, t2 = info >> 4, t = cxv >> 4;
-              const int si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-              int e;
-              switch (shp) {
-                case 0: e = sm.stackp[t * 8 + t2]; break;
-                case 1: case 2: e = e_bulge1 + sm.stackp[t * 8 + t2]; break;
-                case 3: e = sm.int11p[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
-                case 4: e = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); break;
-                case 5: e = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)] - (t2 > 2 ? TermAU : 0); break;
-                case 6: e = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); break;
-                default: e = e_int23 + sm.mm23[cxv] + sm.mm23p[info]; break;   // (2,3), (3,2)
-              }
-              const int v = cpq + e;
-              if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
+          const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
+          for (int q = aw; q < pcnt; q += 2 * NA) {
+            const bool two = q + NA < pcnt;
+            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + NA : q)];
+            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
+            const int w00 = sm.wring[b_off + i0], w01 = sm.wring[o_off + i0];
+            const int w10 = sm.wring[b_off + i1], w11 = sm.wring[o_off + i1];
+            const int n00 = sm.mm1np[w01 & 127], n10 = sm.mm1np[w11 & 127];
+            const int m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+            int e00 = (w00 >> 8) + b_L + ((ij0 >> 4) > 2 ? TermAU : 0), e01 = (w01 >> 8) + o_L + n00 + m0;
+            int e10 = (w10 >> 8) + b_L + ((ij1 >> 4) > 2 ? TermAU : 0), e11 = (w11 >> 8) + o_L + n10 + m1;
+            int v0 = min(b_ok ? e00 : INF, o_ok ? e01 : INF);
+            int v1 = min(b_ok ? e10 : INF, o_ok ? e11 : INF);
+            v0 = wave_min_i32_lane63(v0);
+            v1 = wave_min_i32_lane63(v1);
+            if (lane == WAVE - 1) {
+              if (v0 < HALF) atomicMin(&sm.accI[par][i0 + slot0], v0);
+              if (two && v1 < HALF) atomicMin(&sm.accI[par][i1 + slot0], v1);
             }
           }
         }
+        STAMP(1);
+        // ---- X: the nine fixed small shapes, all by one wave per 64 pairable cells (lane = compacted cell)
+        for (int ch = 0; ch * WAVE < pcnt; ch++) {
+          if (aw != NA - 1 - (ch % NA)) continue;
+          const int q = ch * WAVE + lane;
+          const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+          const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+          int w[9];
+#pragma unroll
+          for (int shp = 0; shp < 9; shp++) {
+            const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull), u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
+            const int dp = d - 2 - u1 - u2;
+            w[shp] = dp > TURN ? sm.wring[(dp & 31) * RS + 1 + u1 + i] : INF * 256;
+          }
+          int e[9];
+          { const int f = w[0] & 127; e[0] = sm.stackp[t * 8 + (f >> 4)]; }
+          { const int f = w[1] & 127; e[1] = e_bulge1 + sm.stackp[t * 8 + (f >> 4)]; }
+          { const int f = w[2] & 127; e[2] = e_bulge1 + sm.stackp[t * 8 + (f >> 4)]; }
+          { const int f = w[3] & 127; e[3] = sm.int11p[(t * 8 + (f >> 4)) * 16 + si1 * 4 + sj1]; }
+          { const int f = w[4] & 127, t2 = f >> 4; e[4] = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((f >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); }
+          { const int f = w[5] & 127, t2 = f >> 4; e[5] = T.int21[(t2 * 8 + t) * 64 + ((f >> 2) & 3) * 16 + si1 * 4 + (f & 3)] - (t2 > 2 ? TermAU : 0); }
+          { const int f = w[6] & 127, t2 = f >> 4; e[6] = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (f & 3) * 16 + ((f >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); }
+          const int m23 = sm.mm23[cxv];
+          e[7] = e_int23 + m23 + sm.mm23p[w[7] & 127];
+          e[8] = e_int23 + m23 + sm.mm23p[w[8] & 127];
+          int v = INF;
+#pragma unroll
+          for (int shp = 0; shp < 9; shp++) v = min(v, (w[shp] >> 8) + e[shp]);
+          if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
+        }
         STAMP(2);
-        // ---- K: multiloop splits, lane = cell, this wave's split points tt = 4 + aw (mod NA)
-        for (int b = tb_lo; b <= tb_hi; b++) {
-          int i = b * WAVE + lane + 1 - sh - off0;
-          i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const int i4 = i * 4;
-          int acc0 = INF, acc1 = INF;
-          int tt = TURN + 1 + aw;
-          for (; tt + NA <= d - TURN - 2; tt += 2 * NA) {
-            const int* o0 = sm.split_off[par][tt];
-            const int* o1 = sm.split_off[par][tt + NA];
-            const int a0 = *reinterpret_cast<const int*>(fmlb + o0[0] + i4), b0 = *reinterpret_cast<const int*>(fmlb + o0[1] + i4);
-            const int a1 = *reinterpret_cast<const int*>(fmlb + o1[0] + i4), b1 = *reinterpret_cast<const int*>(fmlb + o1[1] + i4);
-            acc0 = min(acc0, a0 + b0);
-            acc1 = min(acc1, a1 + b1);
+        // ---- K: multiloop splits.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
+        {
+          const int g = lane >> 4, cl = lane & 15;
+          for (int sb = krank; sb * 16 < ncell; sb += NA) {
+            int i = sb * 16 + cl + 1;
+            const bool act = i <= ncell;
+            i = act ? i : ncell;
+            int acc0 = INF, acc1 = INF;
+            int tt = TURN + 1 + g;
+            for (; tt + 12 <= d - TURN - 2; tt += 16) {
+              const int a0 = sm.fml[sm.rowoff[tt] + i - 1], c0 = sm.fml[sm.rowoff[d - tt - 1] + i + tt];
+              const int a1 = sm.fml[sm.rowoff[tt + 4] + i - 1], c1 = sm.fml[sm.rowoff[d - tt - 5] + i + tt + 4];
+              const int a2 = sm.fml[sm.rowoff[tt + 8] + i - 1], c2 = sm.fml[sm.rowoff[d - tt - 9] + i + tt + 8];
+              const int a3 = sm.fml[sm.rowoff[tt + 12] + i - 1], c3 = sm.fml[sm.rowoff[d - tt - 13] + i + tt + 12];
+              acc0 = min(acc0, min(a0 + c0, a2 + c2));
+              acc1 = min(acc1, min(a1 + c1, a3 + c3));
+            }
+            for (; tt <= d - TURN - 2; tt += 4) acc0 = min(acc0, sm.fml[sm.rowoff[tt] + i - 1] + sm.fml[sm.rowoff[d - tt - 1] + i + tt]);
+            acc0 = min(acc0, acc1);
+            if (act && acc0 < HALF) atomicMin(&sm.accK[par][i + slot0], acc0);
           }
-          if (tt <= d - TURN - 2) {
-            const int* o0 = sm.split_off[par][tt];
-            acc0 = min(acc0, *reinterpret_cast<const int*>(fmlb + o0[0] + i4) + *reinterpret_cast<const int*>(fmlb + o0[1] + i4));
-          }
-          acc0 = min(acc0, acc1);
-          if (acc0 < HALF) atomicMin(&sm.accK[par][b * WAVE + lane], acc0);
         }
         STAMP(5);
       }

@@ -29,7 +29,7 @@ struct PfFastSmem {
   static constexpr int RS = PF_FAST_NMAX + 2;
   static constexpr int NSLOT = 4 * WAVE;
   static constexpr int NL = PF_FAST_NMAX + 8;
-  double qbi[32 * RS];            // qb * expMismatchI(inner side) of the last 32 diagonals
+  double qbi[33 * RS];            // qb * expMismatchI(inner side) of the last 32 diagonals; row 32 stays zero
   double dring[4 * RS];           // D[i,j] = sum_k qm[i,k-1] qm1[k,j] of the last 4 diagonals
   double qm1row[2][RS];           // qm1 of the previous diagonal
   double urow[2][RS];             // U of the previous diagonal
@@ -44,8 +44,8 @@ struct PfFastSmem {
   double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
-  double tw_d[2][32][3];          // per residue: asymmetry factor, size factor, weight of the second boundary term
-  int tw_i[2][32][2];             // per residue: offA | flag, offB (byte offsets into qbi)
+  double tw_d[2][32][3];          // per residue: asymmetry factor, keep factor (0 forgets the previous tenant), size factor
+  int tw_i[2][32][2];             // per residue: byte offsets A, B into qbi
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   unsigned char info[32 * RS];
@@ -67,58 +67,65 @@ template <int NT>
 __device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, const PfTables& T, const double* scale, int d, int tid) {
   constexpr int RS = PfFastSmem<NT>::RS;
   if (tid < GRES) {
+    // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
+    //   G <- G * keep + (ring[A + i] + ring[B + i]) * asym;   contribution = G * size
+    // dead entries: asym = 0, keep = 1, size = 0; entries without an inner pair yet: keep = 0, asym = 0
     const int par = d & 1;
     const int x = (int)((unsigned)(d + 50 - tid) % (unsigned)GRES);     // (d - 6 - rho) mod 28
-    int w0 = TW_DEAD, w1 = 0;
-    double eas = 0.0, W = 0.0, wb = 0.0;
+    const int zero_row = 32 * RS * 8;
+    int offA = zero_row, offB = zero_row;
+    double eas = 0.0, keep = 1.0, W = 0.0;
     if (x <= 26) {
       const int s = x + 4, dp = d - 6 - x;
-      if (dp <= TURN) w0 = TW_KILL;
+      if (dp <= TURN) keep = 0.0;
       else {
         const int base = (dp & 31) * RS * 8;
-        w0 = (base + 3 * 8) | (s <= 5 ? TW_BIRTH : TW_LIVE);
-        w1 = base + (s - 1) * 8;
+        offA = base + 3 * 8;
+        offB = s == 4 ? zero_row : base + (s - 1) * 8;       // s = 4 has the single shape (2,2)
         eas = T.eninio[s - 4];
+        keep = s <= 5 ? 0.0 : 1.0;
         W = s >= 6 ? T.interior[s] * scale[s + 2] : 0.0;
-        wb = s == 4 ? 0.0 : 1.0;
       }
     }
-    sm.tw_i[par][tid][0] = w0; sm.tw_i[par][tid][1] = w1;
-    sm.tw_d[par][tid][0] = eas; sm.tw_d[par][tid][1] = W; sm.tw_d[par][tid][2] = wb;
+    sm.tw_i[par][tid][0] = offA; sm.tw_i[par][tid][1] = offB;
+    sm.tw_d[par][tid][0] = eas; sm.tw_d[par][tid][1] = keep; sm.tw_d[par][tid][2] = W;
   }
 }
 
-template <int NT>
-__device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int par, int i8, int g) {
+__device__ __forceinline__ double lane_table_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int NT, int R0, int R1>
+__device__ __forceinline__ double pf_tower_part(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int i8, int eA, int eB, double eas,
+                                                double ekeep, double eW) {
   const char* ring = reinterpret_cast<const char*>(sm.qbi);
-  // loads first (tables, then ring operands), arithmetic after: two LDS round trips for all entries
-  int w0[PGSLOTS], w1[PGSLOTS];
-  double a[PGSLOTS], b[PGSLOTS];
+  double a[R1 - R0], b[R1 - R0];
 #pragma unroll
-  for (int r = 0; r < PGSLOTS; r++) {
-    const int rho = r * PNG + g;
-    w0[r] = rho < GRES ? sm.tw_i[par][rho][0] : TW_DEAD;
-    w1[r] = rho < GRES ? sm.tw_i[par][rho][1] : 0;
-  }
-#pragma unroll
-  for (int r = 0; r < PGSLOTS; r++) {
-    a[r] = *reinterpret_cast<const double*>(ring + (w0[r] & ~3) + i8);
-    b[r] = *reinterpret_cast<const double*>(ring + w1[r] + i8);
+  for (int r = R0; r < R1; r++) {
+    a[r - R0] = *reinterpret_cast<const double*>(ring + lane_table(eA, r) + i8);
+    b[r - R0] = *reinterpret_cast<const double*>(ring + lane_table(eB, r) + i8);
   }
   double acc = 0.0;
 #pragma unroll
-  for (int r = 0; r < PGSLOTS; r++) {
-    const int rho = r * PNG + g;
-    if (rho >= GRES) continue;
-    const double* e = sm.tw_d[par][rho];
-    const int fl = w0[r] & 3;
-    const double v = (a[r] + e[2] * b[r]) * e[0];
-    double gn = (fl == TW_BIRTH ? 0.0 : G[r]) + v;
-    gn = fl == TW_KILL ? 0.0 : gn;
-    G[r] = fl == TW_DEAD ? G[r] : gn;
-    acc += G[r] * e[1];
+  for (int r = R0; r < R1; r++) {
+    G[r] = G[r] * lane_table_f64(ekeep, r) + (a[r - R0] + b[r - R0]) * lane_table_f64(eas, r);
+    acc += G[r] * lane_table_f64(eW, r);
   }
   return acc;
+}
+
+template <int NT>
+__device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int par, int i8, int g, int lane) {
+  // lane r fetches the table entry of slot r (one LDS round trip for the wave); words are broadcast with v_readlane
+  const int rr = lane * PNG + g;
+  const bool on = lane < PGSLOTS && rr < GRES;
+  const int zero_row = 32 * PfFastSmem<NT>::RS * 8;
+  const int eA = on ? sm.tw_i[par][rr][0] : zero_row, eB = on ? sm.tw_i[par][rr][1] : zero_row;
+  const double eas = on ? sm.tw_d[par][rr][0] : 0.0, ekeep = on ? sm.tw_d[par][rr][1] : 1.0, eW = on ? sm.tw_d[par][rr][2] : 0.0;
+  const double lo = pf_tower_part<NT, 0, PGSLOTS / 2>(sm, G, i8, eA, eB, eas, ekeep, eW);
+  const double hi = pf_tower_part<NT, PGSLOTS / 2, PGSLOTS>(sm, G, i8, eA, eB, eas, ekeep, eW);
+  return lo + hi;
 }
 
 template <int NT>
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
   for (int k = tid; k < 4 * RS; k += NT) sm.dring[k] = 0.0;
+  for (int k = tid; k < RS; k += NT) sm.qbi[32 * RS + k] = 0.0;
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * PNG * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
     const double x_b1 = T.bulge[1] * A.scale[3], x_23 = T.interior[5] * T.eninio[1] * A.scale[7];
     const double sc4 = A.scale[4], sc5 = A.scale[5], sc6 = A.scale[6];
-    const char* qr = reinterpret_cast<const char*>(sm.qbi);
+    const int krank = NB == 4 ? (aw < 3 ? aw : aw >= 9 ? aw - 6 : aw + 3) : aw;   // K work first to waves whose towers die early
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g);
+          const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g, lane) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g, lane);
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
         }
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
           for (int q = aw; q < pcnt; q += 2 * NA) {
             const bool two = q + NA < pcnt;
-            const int pe0 = sm.plist[par][q], pe1 = sm.plist[par][two ? q + NA : q];
+            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + NA : q)];
             const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
             const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
             const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         // ---- K: multiloop sums from L2.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
         {
           const int g = lane >> 4, cl = lane & 15;
-          for (int sb = aw; sb * 16 < ncell; sb += NA) {
+          for (int sb = krank; sb * 16 < ncell; sb += NA) {
             int i = sb * 16 + cl + 1;
             const bool act = i <= ncell;
             i = act ? i : ncell;
