@@ -449,6 +449,20 @@ typedef struct {
 
 #define IDX(i, j) ((size_t)(i) * (size_t)(W) + (size_t)(j))
 
+/* per-thread scratch buffers, reused across calls: a fold allocates ~2 MB of tables, and with one
+ * fold per core the page faults of fresh mmap'ed memory would dominate the timed CPU baseline */
+#define TL_SLOTS 24
+static __thread void *tl_buf[TL_SLOTS];
+static __thread size_t tl_cap[TL_SLOTS];
+static void *tl_get(int slot, size_t bytes) {
+  if (tl_cap[slot] < bytes) {
+    free(tl_buf[slot]);
+    tl_buf[slot] = malloc(bytes);
+    tl_cap[slot] = bytes;
+  }
+  return tl_buf[slot];
+}
+
 static void mfe_fill(const orc_params *P, mfectx *M, const char *seq, int n, const unsigned char *nopair) {
   const int W = n + 2;
   M->n = n;
@@ -461,14 +475,22 @@ static void mfe_fill(const orc_params *P, mfectx *M, const char *seq, int n, con
   }
   M->up[n] = 0;
   size_t W2 = (size_t)W * (size_t)W;
-  M->pty = (unsigned char *)calloc(W2, 1);
-  M->c = (int *)malloc(W2 * sizeof(int));
-  M->fML = (int *)malloc(W2 * sizeof(int));
-  M->fMLt = (int *)malloc(W2 * sizeof(int));
+  M->pty = (unsigned char *)tl_get(0, W2);
+  memset(M->pty, 0, W2);
+  M->c = (int *)tl_get(1, W2 * sizeof(int));
+  M->fML = (int *)tl_get(2, W2 * sizeof(int));
+  M->fMLt = (int *)tl_get(3, W2 * sizeof(int));
   M->f5 = (int *)calloc((size_t)n + 2, sizeof(int));
   int *S = M->S, *c = M->c, *fML = M->fML, *fMLt = M->fMLt;
-  int *DML = (int *)malloc(W2 * sizeof(int)); /* decomp[i][j] = min_u fML[i,u]+fML[u+1,j] */
-  for (size_t k = 0; k < W2; k++) { c[k] = INF; fML[k] = INF; fMLt[k] = INF; DML[k] = INF; }
+  int *DML = (int *)tl_get(4, W2 * sizeof(int)); /* decomp[i][j] = min_u fML[i,u]+fML[u+1,j] */
+  int *ci = (int *)tl_get(5, W2 * sizeof(int));  /* c + mismatchI of the pair seen as the inner pair of a loop */
+  int Lgen[MAXLOOP + 1][MAXLOOP + 2];
+  for (int a = 0; a <= MAXLOOP; a++)
+    for (int b = 0; b <= MAXLOOP + 1; b++) {
+      int u = a + b, nl = MAX2(a, b), ns = MIN2(a, b);
+      Lgen[a][b] = (u <= MAXLOOP) ? P->interior[u] + MIN2(P->max_ninio, (nl - ns) * P->ninio) : INF;
+    }
+  for (size_t k = 0; k < W2; k++) { c[k] = INF; fML[k] = INF; fMLt[k] = INF; DML[k] = INF; ci[k] = INF; }
   for (int i = 1; i <= n; i++)
     for (int j = i + TURN + 1; j <= n; j++) {
       if (nopair && (nopair[i - 1] || nopair[j - 1])) continue;
@@ -487,24 +509,44 @@ static void mfe_fill(const orc_params *P, mfectx *M, const char *seq, int n, con
           d += P->MLclosing + E_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]);
           e = MIN2(e, d);
         }
-        /* interior loops (vrna_E_int_loop) */
+        /* interior loops (vrna_E_int_loop).  Same candidates and energies as E_IntLoop; the generic
+         * shapes (both sides >= 2, not 2x2 / 2x3) read c + mismatchI(inner) precombined in ci[] and a
+         * 31x31 size table, so that loop vectorises -- this oracle is also the timed CPU baseline */
         int pmax = MIN2(j - 2 - TURN, i + MAXLOOP + 1);
+        int egen = INF;
         for (int p = i + 1; p <= pmax; p++) {
+          int u1 = p - i - 1;
           int minq = j - i + p - MAXLOOP - 2;
           if (minq < p + 1 + TURN) minq = p + 1 + TURN;
           const unsigned char *prow = M->pty + IDX(p, 0);
           const int *crow = c + IDX(p, 0);
-          for (int q = j - 1; q >= minq; q--) {
+          int u2max = j - 1 - minq;                 /* u2 = j - q - 1 in [0, u2max] */
+          int g0 = u1 < 2 ? u2max + 1 : (u1 == 2 ? 4 : (u1 == 3 ? 3 : 2));   /* first generic u2 */
+          int sp_hi = MIN2(g0 - 1, u2max);
+          for (int u2 = 0; u2 <= sp_hi; u2++) {
+            int q = j - 1 - u2;
             int t2 = prow[q];
             if (!t2) continue;
             int en = crow[q];
             if (en >= INF) continue;
-            en += E_IntLoop(P, p - i - 1, j - q - 1, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]);
+            en += E_IntLoop(P, u1, u2, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]);
             e = MIN2(e, en);
           }
+          if (g0 <= u2max) {
+            const int *cir = ci + IDX(p, 0) + (j - 1);
+            const int *Lr = Lgen[u1];
+            int m = INF;
+            for (int u2 = g0; u2 <= u2max; u2++) {
+              int v = cir[-u2] + Lr[u2];
+              m = MIN2(m, v);
+            }
+            egen = MIN2(egen, m);
+          }
         }
+        if (egen < INF / 2) e = MIN2(e, egen + P->mmI[t][S[i + 1]][S[j - 1]]);
       }
       c[IDX(i, j)] = e;
+      ci[IDX(i, j)] = (t && e < INF) ? e + P->mmI[RTYPE[t]][S[j + 1]][S[i - 1]] : INF;
       /* fML (vrna_E_ml_stems_fast, dangles=2) */
       int f = INF;
       if (fML[IDX(i + 1, j)] < INF) f = fML[IDX(i + 1, j)] + P->MLbase;
@@ -539,11 +581,10 @@ static void mfe_fill(const orc_params *P, mfectx *M, const char *seq, int n, con
     }
     f5[j] = f;
   }
-  free(DML);
 }
 
 static void mfe_free(mfectx *M) {
-  free(M->S); free(M->up); free(M->pty); free(M->c); free(M->fML); free(M->fMLt); free(M->f5);
+  free(M->S); free(M->up); free(M->f5);   /* the big tables live in the per-thread arena */
 }
 
 /* ViennaRNA mfe.c backtrack(): sector stack; ml: 0 = exterior f5[1..j], 1 = fML[i..j], 2 = pair (i,j) */
@@ -706,21 +747,34 @@ static void pf_fill(const orc_params *P, pfctx *F, const char *seq, int n) {
     F->up[i] = (ch == 'T') ? 'U' : ch;
   }
   F->up[n] = 0;
-  F->pty = (unsigned char *)calloc(W2, 1);
-  F->qb = (double *)calloc(W2, sizeof(double));
-  F->qm = (double *)calloc(W2, sizeof(double));
-  F->qm1 = (double *)calloc(W2, sizeof(double));
+  F->pty = (unsigned char *)tl_get(8, W2);
+  F->qb = (double *)tl_get(9, W2 * sizeof(double));
+  F->qm = (double *)tl_get(10, W2 * sizeof(double));
+  F->qm1 = (double *)tl_get(11, W2 * sizeof(double));
+  memset(F->pty, 0, W2);
+  memset(F->qb, 0, W2 * sizeof(double));
+  memset(F->qm, 0, W2 * sizeof(double));
+  memset(F->qm1, 0, W2 * sizeof(double));
   F->q5 = (double *)calloc((size_t)n + 2, sizeof(double));
   F->scale = (double *)malloc(sizeof(double) * (size_t)(n + 3));
   F->eMLb = (double *)malloc(sizeof(double) * (size_t)(n + 3));
   int *S = F->S;
   double *qb = F->qb, *qm = F->qm, *qm1 = F->qm1, *scale = F->scale, *eMLb = F->eMLb;
-  double *qm1t = (double *)calloc(W2, sizeof(double)); /* qm1t[j][k] = qm1[k][j] */
+  double *qm1t = (double *)tl_get(12, W2 * sizeof(double)); /* qm1t[j][k] = qm1[k][j] */
+  double *qbi = (double *)tl_get(13, W2 * sizeof(double));
+  memset(qm1t, 0, W2 * sizeof(double));
+  memset(qbi, 0, W2 * sizeof(double));  /* qb * expMismatchI of the pair seen as an inner pair */
+  double Wgen[MAXLOOP + 1][MAXLOOP + 2];
   scale[0] = 1.0; eMLb[0] = 1.0;
   for (int k = 1; k <= n + 2; k++) {
     scale[k] = scale[k - 1] / P->pf_scale;
     eMLb[k] = eMLb[k - 1] * P->eMLbase / P->pf_scale; /* expMLbase^k * scale[k] */
   }
+  for (int a = 0; a <= MAXLOOP; a++)
+    for (int b2 = 0; b2 <= MAXLOOP + 1; b2++) {
+      int u = a + b2, nl = MAX2(a, b2), ns = MIN2(a, b2);
+      Wgen[a][b2] = (u <= MAXLOOP && u + 2 <= n + 2) ? P->einterior[u] * P->eninio[nl - ns] * scale[u + 2] : 0.0;
+    }
   for (int i = 1; i <= n; i++)
     for (int j = i + TURN + 1; j <= n; j++) F->pty[IDX(i, j)] = (unsigned char)PAIR[S[i]][S[j]];
   /* ViennaRNA part_func.c fill_arrays: j ascending, i descending */
@@ -732,17 +786,29 @@ static void pf_fill(const orc_params *P, pfctx *F, const char *seq, int n) {
         int u = j - i - 1;
         b = X_Hairpin(P, u, t, S[i + 1], S[j - 1], F->up + i - 1) * scale[u + 2];
         int pmax = MIN2(j - 2 - TURN, i + MAXLOOP + 1);
+        double bgen = 0.0;
         for (int p = i + 1; p <= pmax; p++) {
           int u1 = p - i - 1;
           int minq = j - i + p - MAXLOOP - 2;
           if (minq < p + 1 + TURN) minq = p + 1 + TURN;
-          for (int q = j - 1; q >= minq; q--) {
+          int u2max = j - 1 - minq;
+          int g0 = u1 < 2 ? u2max + 1 : (u1 == 2 ? 4 : (u1 == 3 ? 3 : 2));
+          int sp_hi = MIN2(g0 - 1, u2max);
+          for (int u2 = 0; u2 <= sp_hi; u2++) {
+            int q = j - 1 - u2;
             int t2 = F->pty[IDX(p, q)];
             if (!t2) continue;
-            int u2 = j - q - 1;
             b += qb[IDX(p, q)] * X_IntLoop(P, u1, u2, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]) * scale[u1 + u2 + 2];
           }
+          if (g0 <= u2max) {
+            const double *qir = qbi + IDX(p, 0) + (j - 1);
+            const double *Wr = Wgen[u1];
+            double m = 0.0;
+            for (int u2 = g0; u2 <= u2max; u2++) m += qir[-u2] * Wr[u2];
+            bgen += m;
+          }
         }
+        b += bgen * P->emmI[t][S[i + 1]][S[j - 1]];
         /* multiloop: sum_k qm[i+1,k-1] * qm1[k,j-1] */
         double tmp = 0.0;
         const double *qmrow = qm + IDX(i + 1, 0);
@@ -751,6 +817,7 @@ static void pf_fill(const orc_params *P, pfctx *F, const char *seq, int n) {
         b += tmp * P->eMLclosing * X_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]) * scale[2];
       }
       qb[IDX(i, j)] = b;
+      qbi[IDX(i, j)] = t ? b * P->emmI[RTYPE[t]][S[j + 1]][S[i - 1]] : 0.0;
       /* qm1[i,j] = qm1[i,j-1]*expMLbase[1] + qb*expMLstem */
       double m1 = qm1[IDX(i, j - 1)] * eMLb[1];
       if (t) m1 += b * X_MLstem(P, t, i > 1 ? S[i - 1] : -1, j < n ? S[j + 1] : -1);
@@ -777,11 +844,10 @@ static void pf_fill(const orc_params *P, pfctx *F, const char *seq, int n) {
     }
     q5[j] = q;
   }
-  free(qm1t);
 }
 
 static void pf_free(pfctx *F) {
-  free(F->S); free(F->up); free(F->pty); free(F->qb); free(F->qm); free(F->qm1); free(F->q5);
+  free(F->S); free(F->up); free(F->q5);   /* the big tables live in the per-thread arena */
   free(F->scale); free(F->eMLb);
 }
 

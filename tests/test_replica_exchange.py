@@ -1,0 +1,90 @@
+"""Host-side replica exchange and the N>1 sharding path (gloo, world_size 2, CPU)."""
+import math
+import os
+import random
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rep_temps_ladder():
+    from desirna_amd.replica_exchange import get_rep_temps
+    t = get_rep_temps(64, 10, 150)
+    assert t[:3] == [10, 12.222, 14.444] and t[-2:] == [147.778, 150.0] and len(t) == 64
+    assert get_rep_temps(1, 10, 150) == [150]
+
+
+def test_mc_delta_rng_consumption():
+    from desirna_amd.replica_exchange import mc_delta
+    rng = random.Random(3)
+    assert mc_delta(1.0, 0.5, 10.0, rng) == (True, True)
+    assert rng.random() == random.Random(3).random()          # nothing drawn when the mutant is not worse
+    rng = random.Random(3)
+    ref = random.Random(3)
+    acc, better = mc_delta(1.0, 1.01, 100.0, rng)
+    assert better is False and acc == (math.exp(-504.12 / 100.0 * (1.01 - 1.0)) > ref.random())
+
+
+def test_replica_exchange_swaps_only_temperatures():
+    from desirna_amd.replica_exchange import get_rep_temps, replica_exchange
+    R = 8
+    temps = get_rep_temps(R, 10, 150)
+    scores = [5.0, 4.0, 3.0, 2.0, 1.0, 0.5, 0.2, 0.1]         # hotter replicas are better: every pair swaps
+    new, acc, better, rej = replica_exchange(temps, scores, global_step=1, rng=random.Random(0))
+    assert sorted(new) == sorted(temps) and acc == 4 and better == 4 and rej == 0
+    assert new[0] == temps[1] and new[1] == temps[0]
+    new2, acc2, _, _ = replica_exchange(temps, scores, global_step=2, rng=random.Random(0))
+    assert acc2 == 3 and new2[0] == temps[0] and new2[1] == temps[2] and new2[2] == temps[1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_allgather_and_identical_swaps_gloo_world2(tmp_path):
+    """Two ranks own interleaved replicas, all-gather their scores (gloo) and must take identical swap decisions."""
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, random, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import torch.distributed as dist
+        from desirna_amd.replica_exchange import ReplicaShards, get_rep_temps, replica_exchange
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        R = 13
+        sh = ReplicaShards(R, rank, world)
+        truth = np.random.default_rng(7).normal(size=R)           # what a single process would have
+        full = sh.allgather_scores(truth[sh.local])
+        temps = get_rep_temps(R, 10, 150)
+        rng = random.Random(2137)
+        for step in range(1, 6):
+            temps, acc, better, rej = replica_exchange(temps, list(full), step, rng)
+        print(json.dumps({"rank": rank, "local": sh.local, "full": full.tolist(), "temps": temps}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    port = _free_port()
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0
+        import json
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    truth = np.random.default_rng(7).normal(size=13)
+    assert outs[0]["local"] == list(range(0, 13, 2)) and outs[1]["local"] == list(range(1, 13, 2))
+    for o in outs:
+        assert np.array_equal(np.array(o["full"]), truth)
+    assert outs[0]["temps"] == outs[1]["temps"]
