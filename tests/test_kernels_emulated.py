@@ -73,3 +73,26 @@ def test_eval_kernel(emu, oracle, traj_golden, example_inputs):
 def test_bad_character_flag(emu):
     E, ss, st = emu.mfe(["GGGAAANCCC"], nt=64)
     assert st[0] == 1
+
+
+# ---- LDS-resident production kernels (fold_mfe_lds.hpp / fold_pf_lds.hpp); nt < 0 selects them in the emulator.
+# 256 threads (4 waves: 1 finalize + 3 sweep) cover n <= 64; 1024 threads is the shipped geometry.
+
+@pytest.mark.parametrize("L,nt", [(5, -256), (9, -256), (36, -256), (64, -256), (70, -1024)])
+def test_lds_kernels_random(emu, oracle, L, nt):
+    rng = np.random.default_rng(300 + L)
+    seqs = [_rand(rng, L), _rand(rng, L, "GC")]
+    E, ss, st = emu.mfe(seqs, nt=nt)
+    Ep, stp = emu.pf(seqs, nt=nt)
+    assert not st.any() and not stp.any()
+    for k, s in enumerate(seqs):
+        assert (ss[k], int(E[k])) == oracle.mfe(s), s
+        assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
+
+
+def test_lds_kernel_pk_rounds(emu, oracle, traj_golden):
+    rows = [r for r in traj_golden if r["run"] == "Pseudoknot_design_input" and "[" in r["mfe_ss"]][:3]
+    E, ss, st = emu.mfe([r["sequence"] for r in rows], pk_rounds=3, nt=-256)
+    assert not st.any()
+    for r, got in zip(rows, ss):
+        assert got == r["mfe_ss"]
