@@ -326,4 +326,9 @@ extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, 
   HIP_TRY(hipMemcpy(out, e->d_ws_mfe + off, (size_t)count * 4, hipMemcpyDeviceToHost));
   return DRNA_OK;
 }
+extern "C" int drna_debug_read_pf_ws(drna_engine* e, long long off, int count, double* out) {
+  if (!e || !out) return DRNA_ERR_ARG;
+  HIP_TRY(hipMemcpy(out, e->d_ws_pf + off, (size_t)count * 8, hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
 #endif

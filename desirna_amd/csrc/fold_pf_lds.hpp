@@ -37,7 +37,7 @@ struct PfFastSmem {
   double q5[PF_FAST_NMAX + 2];
   double partG[2][PNG][NSLOT];    // tower sums, one slice per pinned wave
   double partK[2][4][NSLOT];      // multiloop sums, one slice per split-point group
-  double accE[2][NSLOT], accX[2][NSLOT];
+  double accE[2][NSLOT], accX[2][3][NSLOT];   // accX: one slice per group of fixed shapes
   // Boltzmann tables
   double stack[64], mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128], int11[1024], d5[32], d3[32];
   double rinv[128];               // 1 / expMismatchI(info)
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * PNG * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
-  for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) { (&sm.accE[0][0])[k] = 0.0; (&sm.accX[0][0])[k] = 0.0; }
+  for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accE[0][0])[k] = 0.0;
+  for (int k = tid; k < 6 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accX[0][0][0])[k] = 0.0;
   if (tid == 0) { sm.flag = 0; sm.q5[0] = 1.0; }
   __syncthreads();
   const char* seq = A.seqs + (long long)r * n;
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         if (i >= 1 && i <= ncell) {
           const double aG = (sm.partG[par][0][tid] + sm.partG[par][1][tid]) + sm.partG[par][2][tid];
           const double aK = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
-          const double aE = sm.accE[par][tid], aX = sm.accX[par][tid];
+          const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
           sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0; sm.partG[par][2][tid] = 0.0;
           sm.partK[par][0][tid] = 0.0; sm.partK[par][1][tid] = 0.0; sm.partK[par][2][tid] = 0.0; sm.partK[par][3][tid] = 0.0;
-          sm.accE[par][tid] = 0.0; sm.accX[par][tid] = 0.0;
+          sm.accE[par][tid] = 0.0; sm.accX[par][0][tid] = 0.0; sm.accX[par][1][tid] = 0.0; sm.accX[par][2][tid] = 0.0;
           const int j = i + d;
           const int t = pair_type(sm.S[i], sm.S[j]);
           const double tau = t > 2 ? eTau : 1.0;
@@ -356,32 +357,49 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
             }
           }
         }
-        // ---- X: the nine fixed small shapes, all by one wave per 64 pairable cells (lane = compacted cell)
-        for (int ch = 0; ch * WAVE < pcnt; ch++) {
-          if (aw != NA - 1 - (ch % NA)) continue;
+        // ---- X: the nine fixed small shapes in three groups (one sum slice each), a group per wave and per
+        // 64 pairable cells (lane = compacted cell); groups go to the last sweep waves, whose towers die early
+        for (int it = 0; it < 3 * ((pcnt + WAVE - 1) / WAVE); it++) {
+          const int ch = it / 3, grp = it - 3 * ch;
+          if (aw != NA - 1 - (it % NA)) continue;
           const int q = ch * WAVE + lane;
           const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
           const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-          double w[9];
-          int f[9];
+          double sum;
+          if (grp == 0) {
+            // (0,0) (0,1) (1,0) (1,1): LDS tables
+            double w[4];
+            int f[4];
 #pragma unroll
-          for (int shp = 0; shp < 9; shp++) {
-            const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull), u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
-            const int dp = d - 2 - u1 - u2;
-            const int off = (dp & 31) * RS + 1 + u1 + i;
-            w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
-            f[shp] = dp > TURN ? sm.info[off] : 0;
+            for (int shp = 0; shp < 4; shp++) {
+              const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
+              const int dp = d - 2 - u1 - u2;
+              const int off = (dp & 31) * RS + 1 + u1 + i;
+              w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
+              f[shp] = dp > TURN ? sm.info[off] : 0;
+            }
+            sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
+            sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * x_b1;
+            sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sc4;
+          } else if (grp == 1) {
+            // (1,2) (2,1) (2,2): tables in global memory (L2)
+            const int dpa = d - 5, dpb = d - 6;
+            const int oa = (dpa & 31) * RS + 2 + i, ob = (dpa & 31) * RS + 3 + i, oc = (dpb & 31) * RS + 3 + i;
+            const double wa = dpa > TURN ? sm.qbi[oa] : 0.0, wb = dpa > TURN ? sm.qbi[ob] : 0.0, wc = dpb > TURN ? sm.qbi[oc] : 0.0;
+            const int fa = dpa > TURN ? sm.info[oa] : 0, fb = dpa > TURN ? sm.info[ob] : 0, fc = dpb > TURN ? sm.info[oc] : 0;
+            const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
+            const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
+            const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
+            sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sc5 + wc * sm.rinv[fc] * gc * sc6;
+          } else {
+            // (2,3) (3,2)
+            const int dp = d - 7;
+            const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
+            const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
+            const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
+            sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * x_23;
           }
-          double sum = 0.0;
-          { const int t2 = f[0] >> 4; sum += w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + t2] * sc2; }
-          { const int t2 = f[1] >> 4; sum += w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + t2] * x_b1; }
-          { const int t2 = f[2] >> 4; sum += w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + t2] * x_b1; }
-          { const int t2 = f[3] >> 4; sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1] * sc4; }
-          { const int t2 = f[4] >> 4; sum += w[4] * sm.rinv[f[4]] * T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((f[4] >> 2) & 3) * 4 + sj1] * sc5; }
-          { const int t2 = f[5] >> 4; sum += w[5] * sm.rinv[f[5]] * T.int21[(t2 * 8 + t) * 64 + ((f[5] >> 2) & 3) * 16 + si1 * 4 + (f[5] & 3)] * sc5; }
-          { const int t2 = f[6] >> 4; sum += w[6] * sm.rinv[f[6]] * T.int22[(t * 8 + t2) * 256 + si1 * 64 + (f[6] & 3) * 16 + ((f[6] >> 2) & 3) * 4 + sj1] * sc6; }
-          sum += (w[7] * sm.r23[f[7]] + w[8] * sm.r23[f[8]]) * sm.mm23[cxv] * x_23;
-          if (q < pcnt) sm.accX[par][i + slot0] = sum;
+          if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
         }
         // ---- K: multiloop sums from L2.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
         {

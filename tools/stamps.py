@@ -28,3 +28,4 @@ names = ["T", "E", "X", "barrier", "finalize", "K"]
 print("per-wave cycles (block 0), total over %d diagonals" % (L - 4))
 for w in range(16):
     print("wave %2d " % w + "  ".join("%s=%7d" % (names[k], st[w, k]) for k in range(6)), " sum=%d" % st[w, :6].sum())
+
