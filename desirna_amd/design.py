@@ -1,0 +1,264 @@
+"""Batched replica-exchange Monte-Carlo design driver on top of the GPU scoring engine.
+
+Counterpart of the reference's host loop: ``run_functions`` (``DesiRNA.py:333-386``),
+``mutate_sequence_re`` / ``single_replica_design`` (``utils/replica_exchange_monte_carlo.py:176-271``),
+``mutate_sequence`` / ``get_mutation_position`` / ``expand_cases`` (``utils/sequence_utils.py:926-1136``),
+``get_nt_list`` (:454-525), ``initial_sequence_generator`` (:686-763) and ``read_input``
+(``utils/stats_inputs_outputs.py:183-214``).  SURVEY rows a1, a2, a5 (8(f)-1).
+
+What is kept from the reference: the input-file format, IUPAC sequence restraints, the move set (single
+unpaired position / Watson-Crick-or-GU pair move on target pairs), targeted mutations around false
+negatives / false positives of the current MFE structure (+-3 window, per-temperature probability
+``linspace(tm_max, tm_min, R)`` rounded to 2 dp), the initial-sequence rule, Metropolis acceptance and the
+even/odd neighbour exchange, one ``random.Random(replica_index)`` stream per replica re-seeded at every
+exchange step.
+
+What is different by design: the R chains advance in LOCK-STEP -- one proposal per replica, one batched
+``score`` call for all of them, R Metropolis decisions -- instead of R forked Python workers.  Trajectories
+are statistically equivalent, not draw-for-draw identical: the reference itself is not reproducible across
+processes (it iterates over ``set`` objects of strings, whose order depends on PYTHONHASHSEED).
+
+Not supported here (raises): alternative-structure "snake" moves, two-strand inputs, ``-nd``, ``-acgu``.
+"""
+import argparse
+import random
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import energy_scores as es
+from . import replica_exchange as rx
+from .sim_score import pair_table
+
+IUPAC = {
+    'N': ['A', 'C', 'G', 'U'], 'W': ['A', 'U'], 'S': ['C', 'G'], 'M': ['A', 'C'], 'K': ['G', 'U'],
+    'R': ['A', 'G'], 'Y': ['C', 'U'], 'B': ['C', 'G', 'U'], 'D': ['A', 'G', 'U'], 'H': ['A', 'C', 'U'],
+    'V': ['A', 'C', 'G'], 'C': ['C'], 'A': ['A'], 'G': ['G'], 'U': ['U'],
+}
+CAN_PAIR = {'A': ['U'], 'U': ['G', 'A'], 'G': ['U', 'C'], 'C': ['G']}
+WC = {'A': 'U', 'U': 'A', 'G': 'C', 'C': 'G'}
+
+
+def read_input(path):
+    """``>key`` block format of the reference (name, seq_restr, sec_struct, optional seed_seq / alt_sec_struct)."""
+    with open(path, encoding='utf-8') as fh:
+        text = fh.read()
+    data = {}
+    for block in text.lstrip(">").rstrip("\n").split("\n>"):
+        lines = block.split("\n")
+        data[lines[0]] = lines[1:]
+    inp = SimpleNamespace(name=data['name'][0], sec_struct=data['sec_struct'][0].strip(),
+                          seq_restr=data['seq_restr'][0].strip(), seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+    if 'seed_seq' in data:
+        inp.seed_seq = data['seed_seq'][0].strip()
+    if 'alt_sec_struct' in data:
+        inp.alt_sec_structs = [x.strip() for x in data['alt_sec_struct']]
+        inp.alt_sec_struct = inp.alt_sec_structs[0]
+    return inp
+
+
+class DesignProblem:
+    """Target structure + restraints -> per-position letter sets and pairing partners (reference get_nt_list)."""
+
+    def __init__(self, sec_struct, seq_restr=None):
+        if "&" in sec_struct:
+            raise NotImplementedError("two-strand design inputs are not part of the GPU path yet")
+        self.sec_struct = sec_struct
+        n = len(sec_struct)
+        self.seq_restr = seq_restr or "N" * n
+        if len(self.seq_restr) != n:
+            raise ValueError("Secondary structure and sequence restraints are of different length. Check input file.")
+        self.partner = pair_table(sec_struct)                 # all bracket families count as design pairs
+        self.pairs = {(i, int(p)) for i, p in enumerate(self.partner) if p > i}
+        letters = []
+        for ch in self.seq_restr:
+            if ch not in IUPAC:
+                raise ValueError("Not allowed characters in sequence restraints. Check input file.")
+            letters.append(list(IUPAC[ch]))
+        allowed = [list(l) for l in letters]
+        for i, j in self.pairs:
+            pi = sorted({b for a in letters[j] for b in CAN_PAIR[a]} & set(letters[i]))
+            pj = sorted({b for a in letters[i] for b in CAN_PAIR[a]} & set(letters[j]))
+            if not pi or not pj:
+                raise ValueError("Wrong restraints in the input file. Nucleotide %d %s, cannot pair with nucleotide %d %s"
+                                 % (i + 1, letters[i], j + 1, letters[j]))
+            allowed[i], allowed[j] = pi, pj
+        self.letters, self.allowed = letters, allowed
+        self.mutable = [i for i in range(n) if len(allowed[i]) != 1]
+        self.n = n
+
+    def initial_sequence(self, rng):
+        """reference initial_sequence_generator with -acgu off: unpaired -> A, first base of an unpaired stretch (length
+        >= 2) after a paired base -> G (else U), pairs -> random G/C (else A/U) Watson-Crick pair, rest random."""
+        n, part = self.n, self.partner
+        s = list(self.seq_restr)
+        for i in range(n):
+            if part[i] < 0 and "A" in self.letters[i]:
+                s[i] = "A"
+        for i in range(1, n - 1):
+            if part[i] < 0 and part[i - 1] >= 0 and part[i + 1] < 0:
+                if "G" in self.letters[i]:
+                    s[i] = "G"
+                elif "U" in self.letters[i]:
+                    s[i] = "U"
+        for i, j in sorted(self.pairs):
+            a, b = self.allowed[i], self.allowed[j]
+            if "C" in a and "G" in a and "C" in b and "G" in b:
+                s[i] = rng.choice(["C", "G"]); s[j] = WC[s[i]]
+            elif "C" in a and "G" in b:
+                s[i], s[j] = "C", "G"
+            elif "G" in a and "C" in b:
+                s[i], s[j] = "G", "C"
+            elif "A" in a and "U" in a and "A" in b and "U" in b:
+                s[i] = rng.choice(["A", "U"]); s[j] = WC[s[i]]
+            elif "A" in a and "U" in b:
+                s[i], s[j] = "A", "U"
+            elif "U" in a and "A" in b:
+                s[i], s[j] = "U", "A"
+            else:
+                # restraints that only leave G-U wobble pairs (the reference falls through to unconstrained
+                # random letters here): take any compatible pair
+                s[i] = rng.choice(a)
+                s[j] = rng.choice(sorted(set(b) & set(CAN_PAIR[s[i]])) or b)
+        for i in range(n):
+            if s[i] not in "ACGU":
+                s[i] = rng.choice(IUPAC[s[i]])
+        return "".join(s)
+
+    # ---- move set
+    def mutation_position(self, mfe_ss, shelf_index, n_shelves, tm_max, tm_min, point_mutations, rng):
+        if not point_mutations:
+            return rng.choice(self.mutable)
+        q = pair_table(mfe_ss)
+        query = {(i, int(p)) for i, p in enumerate(q) if p > i}
+        mutable = set(self.mutable)
+        false_cases = {x for pr in (self.pairs - query) | (query - self.pairs) for x in pr if x in mutable}
+        if not false_cases:
+            return rng.choice(self.mutable)
+        prob = round(float(np.linspace(tm_max, tm_min, num=n_shelves)[shelf_index]), 2)
+        expanded = sorted({c + k for c in false_cases for k in range(-3, 4) if 0 < c + k <= self.n - 1})
+        pool = rng.choices([expanded, self.mutable], weights=[prob, 1 - prob])[0]
+        return rng.choice(pool)
+
+    def mutate(self, seq, pos, rng):
+        s = list(seq)
+        j = int(self.partner[pos])
+        if j < 0:
+            opts = [x for x in self.allowed[pos] if x != s[pos]] if len(self.allowed[pos]) > 1 else []
+            if opts:
+                s[pos] = rng.choice(opts)
+        else:
+            opts1 = sorted(x for x in self.allowed[pos] if x != s[pos]) if len(self.allowed[pos]) != 1 else list(self.allowed[pos])
+            n1 = rng.choice(opts1)
+            opts2 = sorted(set(self.allowed[j]) & set(CAN_PAIR[n1]))
+            if opts2:
+                s[pos], s[j] = n1, rng.choice(opts2)
+        return "".join(s)
+
+
+def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
+               scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
+               device=0, shards=None, scorer=None, progress=None):
+    """Replica-exchange Monte-Carlo design of one target.  Returns dict(best=ScoreSeq, solved=bool, history=..., stats=...).
+
+    ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
+    own replicas and all-gathers the scores before each exchange attempt."""
+    if input_file.alt_sec_struct is not None:
+        raise NotImplementedError("alternative-structure 'snake' moves are not part of the batched driver yet")
+    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr)
+    pks = "on" if set(input_file.sec_struct) - set(".()&") else "off"
+    opts = SimpleNamespace(oligo_state="none", pks=pks, subopt="off", motifs=None, param="1999",
+                           scoring_f=es.parse_scoring_functions(scoring_f))
+    shards = shards or rx.ReplicaShards(replicas, 0, 1)
+    local = shards.local
+    scorer = scorer or es.ReplicaScorer(input_file, opts, max_replicas=max(1, len(local)), device=device)
+    temps = rx.get_rep_temps(replicas, t_min, t_max)
+    shelves = list(temps)
+    main_rng = random.Random(2137 + seed) if seed else random.Random()
+    init = prob.initial_sequence(main_rng)
+    # input_file.seed_seq is read but ignored, as in the reference
+    cur = scorer.score([init] * len(local)) if local else []
+    for k, r in enumerate(local):
+        cur[k].get_replica_num(r + 1)
+        cur[k].get_temp_shelf(temps[r])
+    best = min(cur, key=lambda s: (s.mcc, s.scoring_function)) if cur else None
+    stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=len(local))
+    t_start = time.time()
+    global_step = 0
+    solved = best is not None and best.mcc == 0.0
+    while True:
+        if steps is not None and global_step >= steps:
+            break
+        if steps is None and time.time() - t_start >= timelimit:
+            break
+        if stop_when_solved and solved:
+            break
+        global_step += 1
+        rngs = [random.Random(r) for r in local]              # re-seeded with the replica index every exchange step
+        for _ in range(exchange):
+            props = []
+            for k, r in enumerate(local):
+                shelf = shelves.index(cur[k].temp_shelf)
+                pos = prob.mutation_position(cur[k].mfe_ss, shelf, replicas, tm_max, tm_min, point_mutations == "on", rngs[k])
+                props.append(prob.mutate(cur[k].sequence, pos, rngs[k]))
+            cand = scorer.score(props)
+            stats["scored"] += len(props)
+            for k in range(len(local)):
+                acc, better = rx.mc_delta(cur[k].scoring_function, cand[k].scoring_function, cur[k].temp_shelf, rngs[k])
+                if acc:
+                    cand[k].get_replica_num(cur[k].replica_num)
+                    cand[k].get_temp_shelf(cur[k].temp_shelf)
+                    cand[k].get_sim_step(global_step)
+                    cur[k] = cand[k]
+                    stats["acc_mc"] += 1
+                    stats["acc_mc_better"] += int(better)
+                    if (cur[k].mcc, cur[k].scoring_function) < (best.mcc, best.scoring_function):
+                        best = cur[k]
+                else:
+                    stats["rej_mc"] += 1
+        solved = solved or any(s.mcc == 0.0 for s in cur)
+        # replica exchange: all ranks see all scores and replay the same swaps on the temperature labels
+        all_scores = shards.allgather_scores([s.scoring_function for s in cur])
+        all_temps = shards.allgather_scores([s.temp_shelf for s in cur])
+        new_temps, acc, _, rej = rx.replica_exchange(list(all_temps), list(all_scores), global_step, main_rng)
+        stats["acc_re"] += acc
+        stats["rej_re"] += rej
+        for k, r in enumerate(local):
+            cur[k].get_temp_shelf(new_temps[r])
+        if progress:
+            progress(global_step, best, stats)
+    stats["elapsed_s"] = time.time() - t_start
+    return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="GPU replica-exchange RNA design (flag names follow DesiRNA.py)")
+    ap.add_argument("-f", "--filename", required=True, dest="name")
+    ap.add_argument("-R", "--replicas", type=int, default=10)
+    ap.add_argument("-e", "--exchange", type=int, default=100)
+    ap.add_argument("-t", "--timelimit", type=int, default=60, dest="timlim")
+    ap.add_argument("-s", "--steps", type=int, default=None)
+    ap.add_argument("-tmin", "--tmin", type=float, default=10, dest="t_min")
+    ap.add_argument("-tmax", "--tmax", type=float, default=150, dest="t_max")
+    ap.add_argument("-sf", "--scoring_function", default="Ed-Epf:1.0", dest="scoring_f")
+    ap.add_argument("-tm", "--target_mutations", default="on", choices=["off", "on"], dest="pm")
+    ap.add_argument("-tm_perc_max", type=float, default=0.7, dest="tm_max")
+    ap.add_argument("-tm_perc_min", type=float, default=0.0, dest="tm_min")
+    ap.add_argument("-seed", "--seed_number", type=int, default=0, dest="in_seed")
+    ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
+    a = ap.parse_args(argv)
+    inp = read_input(a.name)
+    res = run_design(inp, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
+                     t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
+                     seed=a.in_seed, stop_when_solved=a.sws == "on")
+    b = res["best"]
+    print("Design solved succesfully!" if res["solved"] else "Design not solved.")
+    print(b.sequence)
+    print(b.mfe_ss)
+    print("Epf=%.3f Ed=%.3f 1-MCC=%.3f score=%.3f  steps=%d scored=%d in %.1fs" %
+          (b.Epf, b.edesired, b.mcc, b.scoring_function, res["steps"], res["stats"]["scored"], res["stats"]["elapsed_s"]))
+
+
+if __name__ == "__main__":
+    main()

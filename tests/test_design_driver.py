@@ -1,0 +1,101 @@
+"""Batched design driver (host side): constraints, move set, and a full REMC run.  The CPU tests drive the
+loop with an ORACLE-backed scorer (test infrastructure); the GPU test runs BASELINE config 1 through the engine."""
+import random
+from types import SimpleNamespace
+
+import pytest
+
+from desirna_amd import design
+from desirna_amd.energy_scores import ScoreSeq, parse_scoring_functions
+from desirna_amd.sim_score import batch_metrics
+
+ETE1 = "(((((......)))))"
+
+
+class OracleScorer:
+    """Same contract as energy_scores.ReplicaScorer.score, numbers from the CPU oracle (tests only)."""
+
+    def __init__(self, oracle, target, scoring_f):
+        self.o, self.target, self.sf = oracle, target, scoring_f
+        self.pk = bool(set(target) - set(".()"))
+
+    def score(self, seqs):
+        out = []
+        for s in seqs:
+            ss, _ = self.o.mfe(s)
+            if self.pk:
+                ss = self.o.pk_struct(s, ss)
+            sc = ScoreSeq(s)
+            sc.get_Epf(self.o.pf(s))
+            sc.get_mfe_ss(ss)
+            sc.get_edesired(self.o.eval_structure(s, self.target) / 100.0)
+            sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
+            mcc, rec, prec = batch_metrics(self.target, [ss])[0]
+            sc.get_precision(prec); sc.get_recall(rec); sc.get_mcc(mcc)
+            sc.get_scoring_function(self.sf)
+            out.append(sc)
+        return out
+
+
+def test_problem_constraints_and_moves():
+    p = design.DesignProblem("((((....))))..", "NNNSNNNNWNNNNA")
+    assert p.allowed[13] == ["A"] and 13 not in p.mutable
+    assert p.allowed[3] == ["G"] and p.allowed[8] == ["U"]        # S pairs with W -> only G-U survives
+    rng = random.Random(1)
+    s = p.initial_sequence(rng)
+    assert len(s) == 14 and set(s) <= set("ACGU") and s[13] == "A"
+    for i, j in p.pairs:
+        assert s[j] in design.CAN_PAIR[s[i]]
+    for _ in range(200):
+        pos = rng.choice(p.mutable)
+        m = p.mutate(s, pos, rng)
+        for i, j in p.pairs:
+            assert m[j] in design.CAN_PAIR[m[i]]
+        assert m[13] == "A"
+        s = m
+    with pytest.raises(ValueError):
+        design.DesignProblem("(....)", "ANNNNC")
+
+
+def test_targeted_position_window():
+    p = design.DesignProblem(ETE1)
+    rng = random.Random(0)
+    # current structure misses everything: all target pairs are false negatives -> window covers 1..15
+    hits = {p.mutation_position("." * 16, 0, 4, 1.0, 1.0, True, rng) for _ in range(300)}
+    assert hits <= set(range(1, 16)) and len(hits) > 8
+    assert p.mutation_position(ETE1, 0, 4, 0.7, 0.0, True, rng) in p.mutable    # solved: uniform choice
+
+
+def test_read_input_format(tmp_path):
+    f = tmp_path / "in.txt"
+    f.write_text(">name\nX\n>seq_restr\nNNNNNNNNNNNNNNNN\n>sec_struct\n%s\n" % ETE1)
+    inp = design.read_input(str(f))
+    assert inp.name == "X" and inp.sec_struct == ETE1 and inp.alt_sec_struct is None
+
+
+def test_design_run_solves_eterna1_with_oracle_scorer(oracle):
+    inp = SimpleNamespace(name="ete1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    sc = OracleScorer(oracle, ETE1, parse_scoring_functions("Ed-Epf:1.0"))
+    res = design.run_design(inp, replicas=4, exchange=20, steps=6, seed=5, scorer=sc, stop_when_solved=True)
+    assert res["solved"] and res["best"].mfe_ss == ETE1 and res["best"].mcc == 0.0
+    assert res["stats"]["scored"] >= 4
+
+
+@pytest.mark.gpu
+def test_config1_design_run_on_gpu(eterna_targets):
+    """BASELINE configs[0] plumbing on the GPU: Eterna100 V1 #1, R=4, -sf Ed-Epf."""
+    tg = eterna_targets["eteV1_01.txt"]
+    inp = SimpleNamespace(name="ete1", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design(inp, replicas=4, exchange=50, steps=10, seed=3, stop_when_solved=True)
+    assert res["solved"] and res["best"].mfe_ss == tg
+
+
+@pytest.mark.gpu
+def test_design_run_L100_on_gpu(eterna_targets):
+    tg = eterna_targets["eteV1_92.txt"]
+    inp = SimpleNamespace(name="ete92", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design(inp, replicas=16, exchange=100, steps=4, seed=1)
+    assert res["best"].mcc < 0.6 and res["stats"]["scored"] == 16 + 4 * 100 * 16
