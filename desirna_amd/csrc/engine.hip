@@ -18,6 +18,7 @@
 #include "fold_mfe_lds.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
+#include "host_driver.hpp"
 #include "tables.hpp"
 
 using namespace drna;
@@ -316,6 +317,113 @@ extern "C" int drna_last_timing(const drna_engine* e, float out[4]) {
 extern "C" int drna_info(const drna_engine* e, int64_t out[6]) {
   if (!e || !out) return DRNA_ERR_ARG;
   out[0] = e->device; out[1] = e->max_R; out[2] = e->max_L; out[3] = e->nt; out[4] = e->cus; out[5] = (int64_t)e->ws_bytes;
+  return DRNA_OK;
+}
+
+// ---------------------------------------------------------------- host-side batched MC helpers (no device work)
+
+extern "C" int drna_simscore_batch(int R, int L, const char* ref, const char* queries, double* mcc, double* recall,
+                                   double* precision) {
+  using namespace drna_host;
+  if (R < 0 || L < 1 || L > 2048 || !ref || (R > 0 && (!queries || !mcc || !recall || !precision))) return DRNA_ERR_ARG;
+  std::vector<int> pr(L), pq(L);
+  if (!pair_table(ref, L, pr.data())) return DRNA_ERR_STRUCTURE;
+  for (int r = 0; r < R; r++) {
+    if (!pair_table(queries + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
+    long tp = 0, fp = 0, fn = 0, tn = 0;
+    for (int i = 0; i < L; i++) {
+      if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }
+      else if (pr[i] == -1) fp++;
+      else fn++;
+    }
+    double num, den;
+    if (tp == 0 && fp == 0 && fn == 0 && tn != 0) { num = 1; den = 1; }
+    else {
+      num = (double)(tp * tn) - (double)(fp * fn);
+      den = std::sqrt((double)((tp + fp) * (tp + fn) * (tn + fn) * (tn + fp)));
+    }
+    mcc[r] = py_round3(num / (den + 0.00001));
+    recall[r] = py_round3((double)tp / ((double)(tp + fn) + 0.001));
+    precision[r] = py_round3((double)tp / ((double)(tp + fp) + 0.001));
+  }
+  return DRNA_OK;
+}
+
+extern "C" int drna_propose_batch(int R, int L, const char* target, const unsigned char* allowed_mask, const char* seqs,
+                                  const char* mfe_ss, const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min,
+                                  int targeted, uint64_t* rng_state, char* out_seqs) {
+  using namespace drna_host;
+  if (R < 0 || L < 1 || L > 2048 || !target || !allowed_mask || (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
+    return DRNA_ERR_ARG;
+  static const char LET[4] = {'A', 'C', 'G', 'U'};
+  static const unsigned CANPAIR[4] = {8u, 4u, 2u | 8u, 1u | 4u};   // A-U, C-G, G-C/U, U-A/G
+  std::vector<int> pt(L), pq(L), mutable_pos, pool;
+  std::vector<char> mark(L);
+  if (!pair_table(target, L, pt.data())) return DRNA_ERR_STRUCTURE;
+  for (int i = 0; i < L; i++)
+    if (__builtin_popcount(allowed_mask[i] & 15u) != 1) mutable_pos.push_back(i);
+  if (mutable_pos.empty()) return DRNA_ERR_ARG;
+  auto letter_index = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
+  for (int r = 0; r < R; r++) {
+    uint64_t& st = rng_state[r];
+    const char* s = seqs + (size_t)r * L;
+    char* o = out_seqs + (size_t)r * L;
+    std::memcpy(o, s, (size_t)L);
+    int pos = -1;
+    if (targeted) {
+      if (!pair_table(mfe_ss + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
+      std::fill(mark.begin(), mark.end(), 0);
+      bool any = false;
+      for (int i = 0; i < L; i++)
+        if (pt[i] != pq[i] && (pt[i] >= 0 || pq[i] >= 0) && __builtin_popcount(allowed_mask[i] & 15u) != 1) {
+          any = true;                                       // end of a false-negative or false-positive pair
+          for (int k = -3; k <= 3; k++) { const int x = i + k; if (x > 0 && x <= L - 1) mark[x] = 1; }
+        }
+      if (any) {
+        double p = n_shelves > 1 ? tm_max + (tm_min - tm_max) * (double)shelf_index[r] / (double)(n_shelves - 1) : tm_max;
+        char buf[32]; snprintf(buf, sizeof buf, "%.2f", p); p = strtod(buf, nullptr);
+        if (rnd01(st) < p) {
+          pool.clear();
+          for (int i = 0; i < L; i++) if (mark[i]) pool.push_back(i);
+          pos = pool[rnd_below(st, (int)pool.size())];
+        }
+      }
+    }
+    if (pos < 0) pos = mutable_pos[rnd_below(st, (int)mutable_pos.size())];
+    const unsigned am = allowed_mask[pos] & 15u;
+    const int cur = letter_index(s[pos]);
+    const int j = pt[pos];
+    if (j < 0) {
+      unsigned opts = __builtin_popcount(am) > 1 ? (am & ~(1u << cur)) : 0u;
+      if (opts) {
+        int k = rnd_below(st, __builtin_popcount(opts));
+        for (int b = 0; b < 4; b++) if (opts & (1u << b)) { if (!k--) { o[pos] = LET[b]; break; } }
+      }
+    } else {
+      unsigned o1 = __builtin_popcount(am) != 1 ? (am & ~(1u << cur)) : am;
+      if (!o1) o1 = am;
+      int k = rnd_below(st, __builtin_popcount(o1));
+      int n1 = 0;
+      for (int b = 0; b < 4; b++) if (o1 & (1u << b)) { if (!k--) { n1 = b; break; } }
+      const unsigned o2 = (allowed_mask[j] & 15u) & CANPAIR[n1];
+      if (o2) {
+        int k2 = rnd_below(st, __builtin_popcount(o2));
+        for (int b = 0; b < 4; b++) if (o2 & (1u << b)) { if (!k2--) { o[pos] = LET[n1]; o[j] = LET[b]; break; } }
+      }
+    }
+  }
+  return DRNA_OK;
+}
+
+extern "C" int drna_metropolis_batch(int R, const double* score_o, const double* score_m, const double* temps, double Lconst,
+                                     uint64_t* rng_state, unsigned char* accept, unsigned char* better) {
+  if (R < 0 || (R > 0 && (!score_o || !score_m || !temps || !rng_state || !accept || !better))) return DRNA_ERR_ARG;
+  for (int r = 0; r < R; r++) {
+    if (score_m[r] <= score_o[r]) { accept[r] = 1; better[r] = 1; continue; }
+    better[r] = 0;
+    const double p = std::exp((-Lconst / temps[r]) * (score_m[r] - score_o[r]));
+    accept[r] = p > drna_host::rnd01(rng_state[r]) ? 1 : 0;      // one draw, only when the mutant is worse
+  }
   return DRNA_OK;
 }
 

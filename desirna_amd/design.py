@@ -232,6 +232,100 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
     return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step}
 
 
+def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
+                    scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
+                    device=0, engine=None):
+    """Same loop as :func:`run_design` with the per-replica host work in native code and no per-step Python objects:
+    proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.
+    Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
+    from . import engine as _engine
+    if input_file.alt_sec_struct is not None:
+        raise NotImplementedError("alternative-structure 'snake' moves are not part of the batched driver yet")
+    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr)
+    sf = es.parse_scoring_functions(scoring_f)
+    for name, _ in sf:
+        if name not in es.AVAILABLE_SCORING_FUNCTIONS:
+            raise ValueError("%s is not an available option for scoring function. Check your command." % name)
+        if name == "Edef":
+            raise NotImplementedError("Edef (ensemble defect) needs the outside recursion: not on the GPU path yet")
+    R, L = replicas, prob.n
+    eng = engine or _engine.Engine(max_R=R, max_L=L, device=device)
+    hk = _engine.HostKernels()
+    eng.set_targets([input_file.sec_struct])
+    flags = _engine.NEED_PF | _engine.NEED_MFE | _engine.NEED_EVAL
+    if set(input_file.sec_struct) - set(".()&"):
+        flags |= _engine.NEED_PK
+    amask = np.array([sum(1 << "ACGU".index(c) for c in a) for a in prob.allowed], dtype=np.uint8)
+    temps = np.array(rx.get_rep_temps(R, t_min, t_max), dtype=np.float64)
+    shelves = temps.copy()
+    main_rng = random.Random(2137 + seed) if seed else random.Random()
+    ref_ss = input_file.sec_struct
+
+    def score(seqs_u8):
+        Epf, Emfe, ss, Ed = eng.score_batch_arrays(seqs_u8, flags)
+        mcc, rec, prec = hk.simscore(ref_ss, ss)
+        ed = Ed[:, 0] / 100.0
+        total = np.zeros(len(Epf))
+        for name, w in sf:
+            if name == "Ed-Epf":
+                total += (ed - Epf) * w
+            elif name == "1-MCC":
+                total += (1 - mcc) * 10 * w
+            elif name == "sln_Epf":
+                total += (Epf + 0.3759 * L + 5.7534) / 10 * w
+            elif name == "Ed-MFE":
+                total += (ed - Emfe / 100.0) * w
+            elif name == "1-precision":
+                total += (1 - prec) * 10 * w
+            elif name == "1-recall":
+                total += (1 - rec) * 10 * w
+        return total, 1 - mcc, ss, Epf, ed
+
+    init = prob.initial_sequence(main_rng)
+    cur = np.tile(np.frombuffer(init.encode(), dtype=np.uint8), (R, 1)).copy()
+    cur_score, cur_mcc, cur_ss, cur_epf, cur_ed = score(cur)
+    k0 = int(np.lexsort((cur_score, cur_mcc))[0])
+    best = dict(sequence=cur[k0].tobytes().decode(), mfe_ss=cur_ss[k0].tobytes().decode(), mcc=float(cur_mcc[k0]),
+                scoring_function=float(cur_score[k0]), Epf=float(cur_epf[k0]), edesired=float(cur_ed[k0]))
+    stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=R)
+    t_start = time.time()
+    step = 0
+    solved = best["mcc"] == 0.0
+    targeted = point_mutations == "on"
+    while True:
+        if steps is not None and step >= steps:
+            break
+        if steps is None and time.time() - t_start >= timelimit:
+            break
+        if stop_when_solved and solved:
+            break
+        step += 1
+        rng_state = np.arange(R, dtype=np.uint64)                # re-seeded with the replica index every exchange step
+        shelf_idx = np.searchsorted(shelves, temps).astype(np.int32)
+        for _ in range(exchange):
+            prop = hk.propose(ref_ss, amask, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
+            p_score, p_mcc, p_ss, p_epf, p_ed = score(prop)
+            acc, better = hk.metropolis(cur_score, p_score, temps, rng_state)
+            cur[acc] = prop[acc]; cur_ss[acc] = p_ss[acc]
+            cur_score[acc] = p_score[acc]; cur_mcc[acc] = p_mcc[acc]; cur_epf[acc] = p_epf[acc]; cur_ed[acc] = p_ed[acc]
+            na = int(acc.sum())
+            stats["acc_mc"] += na
+            stats["acc_mc_better"] += int((acc & better).sum())
+            stats["rej_mc"] += R - na
+            stats["scored"] += R
+            kb = int(np.lexsort((cur_score, cur_mcc))[0])
+            if (cur_mcc[kb], cur_score[kb]) < (best["mcc"], best["scoring_function"]):
+                best = dict(sequence=cur[kb].tobytes().decode(), mfe_ss=cur_ss[kb].tobytes().decode(), mcc=float(cur_mcc[kb]),
+                            scoring_function=float(cur_score[kb]), Epf=float(cur_epf[kb]), edesired=float(cur_ed[kb]))
+        solved = solved or bool((cur_mcc == 0.0).any())
+        new_temps, a, _, rj = rx.replica_exchange(list(temps), list(cur_score), step, main_rng)
+        temps = np.array(new_temps, dtype=np.float64)
+        stats["acc_re"] += a
+        stats["rej_re"] += rj
+    stats["elapsed_s"] = time.time() - t_start
+    return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="GPU replica-exchange RNA design (flag names follow DesiRNA.py)")
     ap.add_argument("-f", "--filename", required=True, dest="name")
@@ -247,9 +341,10 @@ def main(argv=None):
     ap.add_argument("-tm_perc_min", type=float, default=0.0, dest="tm_min")
     ap.add_argument("-seed", "--seed_number", type=int, default=0, dest="in_seed")
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
+    ap.add_argument("--python-host", action="store_true", help="per-replica Python host loop instead of the native batched one")
     a = ap.parse_args(argv)
     inp = read_input(a.name)
-    res = run_design(inp, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
+    res = (run_design if a.python_host else run_design_fast)(inp, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
                      t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
                      seed=a.in_seed, stop_when_solved=a.sws == "on")
     b = res["best"]

@@ -22,7 +22,8 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
            -5: "unbalanced structure", -6: "partition function out of fp64 range", -7: "internal (traceback)"}
 
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
-           "drna_score_batch_device", "drna_last_timing", "drna_info")
+           "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
+           "drna_metropolis_batch")
 
 
 class EngineError(RuntimeError):
@@ -56,6 +57,12 @@ def load_library(path=None):
     L.drna_last_timing.argtypes = [vp, vp]
     L.drna_info.restype = ci
     L.drna_info.argtypes = [vp, vp]
+    L.drna_simscore_batch.restype = ci
+    L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
+    L.drna_propose_batch.restype = ci
+    L.drna_propose_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp, ci, C.c_double, C.c_double, ci, vp, vp]
+    L.drna_metropolis_batch.restype = ci
+    L.drna_metropolis_batch.argtypes = [ci, vp, vp, vp, C.c_double, vp, vp, vp]
     return L
 
 
@@ -116,6 +123,19 @@ class Engine:
         return {"Epf": Epf, "Emfe": Emfe,
                 "mfe_ss": [bytes(r).decode("ascii") for r in ss] if ss is not None else None, "Ed": Ed}
 
+    def score_batch_arrays(self, seqs_u8, flags=NEED_PF | NEED_MFE | NEED_EVAL):
+        """Array form for hot host loops: seqs_u8 is an (R, L) uint8 array of ASCII letters; returns
+        (Epf float64[R], Emfe int32[R], mfe_ss uint8[R, L], Ed int32[R, n_targets]) without building Python strings."""
+        seqs_u8 = np.ascontiguousarray(seqs_u8, dtype=np.uint8)
+        R, L = seqs_u8.shape
+        Epf = np.zeros(R, dtype=np.float64)
+        Emfe = np.zeros(R, dtype=np.int32)
+        ss = np.zeros((R, L), dtype=np.uint8)
+        Ed = np.zeros((R, max(1, self.n_targets)), dtype=np.int32)
+        self._check(self._L.drna_score_batch(self._h, R, L, seqs_u8.ctypes.data_as(C.c_char_p), flags,
+                                             Epf.ctypes.data, Emfe.ctypes.data, ss.ctypes.data, Ed.ctypes.data))
+        return Epf, Emfe, ss, Ed
+
     def score_batch_device(self, d_seqs, R, L, flags, d_Epf=None, d_Emfe=None, d_ss=None, d_Ed=None):
         """Device-resident variant: arguments are raw device pointers (e.g. ``tensor.data_ptr()``).
         The caller must have made the inputs visible (``torch.cuda.synchronize()``) before the call."""
@@ -132,3 +152,50 @@ class Engine:
         self._check(self._L.drna_info(self._h, out))
         return {"device": out[0], "max_R": out[1], "max_L": out[2], "threads_per_wg": out[3],
                 "compute_units": out[4], "workspace_bytes": out[5]}
+
+
+class HostKernels:
+    """Native batched host helpers of the MC inner loop (no GPU needed): SimScore, proposals, Metropolis."""
+
+    def __init__(self, lib=None):
+        self._L = load_library(lib)
+
+    def simscore(self, ref, queries_u8):
+        """ref: reference structure string ('&' -> 'Ee' already applied); queries_u8: (R, L) uint8.
+        Returns rounded (mcc, recall, precision) arrays exactly as the reference's SimScore computes them."""
+        q = np.ascontiguousarray(queries_u8, dtype=np.uint8)
+        R, L = q.shape
+        mcc, rec, prec = np.zeros(R), np.zeros(R), np.zeros(R)
+        rc = self._L.drna_simscore_batch(R, L, ref.encode("ascii"), q.ctypes.data, mcc.ctypes.data, rec.ctypes.data,
+                                         prec.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_simscore_batch")
+        return mcc, rec, prec
+
+    def propose(self, target, allowed_mask, seqs_u8, ss_u8, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state):
+        s = np.ascontiguousarray(seqs_u8, dtype=np.uint8)
+        R, L = s.shape
+        out = np.empty_like(s)
+        ss = np.ascontiguousarray(ss_u8, dtype=np.uint8)
+        am = np.ascontiguousarray(allowed_mask, dtype=np.uint8)
+        sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
+        assert rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+        rc = self._L.drna_propose_batch(R, L, target.encode("ascii"), am.ctypes.data, s.ctypes.data, ss.ctypes.data,
+                                        sh.ctypes.data, int(n_shelves), float(tm_max), float(tm_min), int(bool(targeted)),
+                                        rng_state.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_propose_batch")
+        return out
+
+    def metropolis(self, score_o, score_m, temps, rng_state, L_const=504.12):
+        so = np.ascontiguousarray(score_o, dtype=np.float64)
+        sm = np.ascontiguousarray(score_m, dtype=np.float64)
+        tt = np.ascontiguousarray(temps, dtype=np.float64)
+        R = so.shape[0]
+        acc = np.zeros(R, dtype=np.uint8)
+        bet = np.zeros(R, dtype=np.uint8)
+        rc = self._L.drna_metropolis_batch(R, so.ctypes.data, sm.ctypes.data, tt.ctypes.data, float(L_const),
+                                           rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_metropolis_batch")
+        return acc.astype(bool), bet.astype(bool)

@@ -100,6 +100,38 @@ int drna_last_timing(const drna_engine *e, float out[4]);
  * out[4]=compute units, out[5]=bytes of device workspace */
 int drna_info(const drna_engine *e, int64_t out[6]);
 
+/*
+ * Host-side pieces of the Monte-Carlo inner loop, batched over replicas (plain CPU code, no engine needed).
+ *
+ * drna_simscore_batch: SimScore(ref, query) of utils/sim_score.py:62-147 for R query structures against one
+ * reference; outputs are the reference's rounded mcc / recall / precision (NOT 1 - x).  '&' must already be
+ * replaced by "Ee" as utils/energy_scores.py:79 does.
+ */
+int drna_simscore_batch(int R, int L, const char *ref, const char *queries, double *mcc, double *recall,
+                        double *precision);
+
+/*
+ * drna_propose_batch: one proposal per replica, the move set of mutate_sequence / get_mutation_position /
+ * expand_cases (utils/sequence_utils.py:926-1136) for single-chain targets without alternative structures.
+ *   target        L chars, every bracket family is a design pair
+ *   allowed_mask  L bytes, bit0 A, bit1 C, bit2 G, bit3 U: letters_allowed of get_nt_list (:454-525)
+ *   seqs, mfe_ss  R*L chars: current sequence and current MFE structure of each replica
+ *   shelf_index   R ints: index of the replica's temperature shelf; the targeted-mutation probability is
+ *                 round(linspace(tm_max, tm_min, n_shelves)[index], 2) (:963-967)
+ *   rng_state     R uint64, one stream per replica, advanced in place
+ *   out_seqs      R*L chars
+ */
+int drna_propose_batch(int R, int L, const char *target, const unsigned char *allowed_mask, const char *seqs,
+                       const char *mfe_ss, const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min,
+                       int targeted, uint64_t *rng_state, char *out_seqs);
+
+/*
+ * drna_metropolis_batch: mc_delta of utils/replica_exchange_monte_carlo.py:26-57 for R replicas: accept iff
+ * score_m <= score_o, else with probability exp(-Lconst / T * (score_m - score_o)) (one draw, only then).
+ */
+int drna_metropolis_batch(int R, const double *score_o, const double *score_m, const double *temps, double Lconst,
+                          uint64_t *rng_state, unsigned char *accept, unsigned char *better);
+
 #ifdef __cplusplus
 }
 #endif

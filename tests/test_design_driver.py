@@ -99,3 +99,74 @@ def test_design_run_L100_on_gpu(eterna_targets):
                           alt_sec_structs=None)
     res = design.run_design(inp, replicas=16, exchange=100, steps=4, seed=1)
     assert res["best"].mcc < 0.6 and res["stats"]["scored"] == 16 + 4 * 100 * 16
+
+
+# ---- native batched host helpers (no GPU needed: plain CPU code in the C-ABI library)
+
+@pytest.fixture(scope="module")
+def hk():
+    import __graft_entry__ as g
+    g.build()
+    from desirna_amd.engine import HostKernels
+    return HostKernels()
+
+
+def test_native_simscore_matches_reference_columns(hk, traj_golden, example_inputs):
+    import numpy as np
+    for run in ("Standard_design_input", "Pseudoknot_design_input", "RNA_RNA_complex_design_input"):
+        rows = [r for r in traj_golden if r["run"] == run]
+        ref = example_inputs[run]["sec_struct"][0].replace("&", "Ee")
+        q = np.array([np.frombuffer(r["mfe_ss"].replace("&", "Ee").encode(), dtype=np.uint8) for r in rows])
+        mcc, rec, prec = hk.simscore(ref, q)
+        for k, r in enumerate(rows):
+            assert 1 - mcc[k] == float(r["one_minus_mcc"]) and 1 - rec[k] == float(r["one_minus_recall"])
+            assert 1 - prec[k] == float(r["one_minus_precision"])
+
+
+def test_native_proposals_respect_constraints(hk):
+    import numpy as np
+    target = "((((....))))..[[..]]"
+    restr = "NNNSNNNNWNNNNANNNNNN"
+    p = design.DesignProblem(target, restr)
+    amask = np.array([sum(1 << "ACGU".index(c) for c in a) for a in p.allowed], dtype=np.uint8)
+    R = 32
+    seq = p.initial_sequence(random.Random(2))
+    cur = np.tile(np.frombuffer(seq.encode(), dtype=np.uint8), (R, 1)).copy()
+    ss = np.tile(np.frombuffer(("." * len(target)).encode(), dtype=np.uint8), (R, 1)).copy()
+    rng = np.arange(R, dtype=np.uint64)
+    changed = 0
+    for it in range(60):
+        out = hk.propose(target, amask, cur, ss, np.zeros(R, dtype=np.int32), R, 0.7, 0.0, True, rng)
+        for r in range(R):
+            s = out[r].tobytes().decode()
+            assert all(s[i] in p.allowed[i] for i in range(len(s)))
+            for i, j in p.pairs:
+                assert s[j] in design.CAN_PAIR[s[i]]
+            d = sum(a != b for a, b in zip(s, cur[r].tobytes().decode()))
+            assert d <= 2
+            changed += d > 0
+        cur = out
+    assert changed > 0.8 * 60 * R
+    # two replicas with the same stream state and the same inputs make the same move
+    rng2 = np.array([7, 7], dtype=np.uint64)
+    o2 = hk.propose(target, amask, cur[:2] * 0 + cur[0], ss[:2], np.zeros(2, dtype=np.int32), R, 0.7, 0.0, True, rng2)
+    assert (o2[0] == o2[1]).all()
+
+
+def test_native_metropolis_semantics(hk):
+    import numpy as np
+    rng = np.arange(4, dtype=np.uint64)
+    before = rng.copy()
+    acc, better = hk.metropolis([1.0, 1.0, 1.0, 1.0], [0.5, 1.0, 1.0 + 1e-9, 50.0], [10.0, 10.0, 1e9, 10.0], rng)
+    assert list(acc[:2]) == [True, True] and list(better) == [True, True, False, False]
+    assert acc[2] and not acc[3]                     # tiny uphill at huge T is accepted, huge uphill is not
+    assert (rng[:2] == before[:2]).all() and (rng[2:] != before[2:]).all()   # a draw only when the mutant is worse
+
+
+@pytest.mark.gpu
+def test_fast_driver_solves_L200_on_gpu(eterna_targets):
+    tg = eterna_targets["eteV1_69.txt"]
+    inp = SimpleNamespace(name="ete69", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design_fast(inp, replicas=64, exchange=100, steps=6, seed=1, stop_when_solved=True)
+    assert res["solved"] and res["stats"]["scored"] >= 64
