@@ -57,6 +57,20 @@ __device__ __forceinline__ int lane_table(int v, int l) { return __builtin_amdgc
 // LDS read into ds_read + s_waitcnt lgkmcnt(0) + v_readfirstlane: a full LDS round trip per value, serialised.
 __device__ __forceinline__ int as_vector(int x) { return __builtin_amdgcn_update_dpp(x, x, 0xE4, 0xF, 0xF, false); }
 
+// Pin a loop-invariant value loaded from global memory in registers: without this hipcc re-executes the load
+// inside the diagonal loop (cheaper in registers, but a full L2 round trip per diagonal on the critical path).
+__device__ __forceinline__ int keep_i32(int x) { return as_vector(x); }
+__device__ __forceinline__ double keep_f64(double x) {
+  return __hiloint2double(as_vector(__double2hiint(x)), as_vector(__double2loint(x)));
+}
+
+// Pop one item index from a workgroup work queue in LDS (lane 0 does the atomic, the wave gets the value)
+__device__ __forceinline__ int queue_pop(int* head, int lane) {
+  int it = 0;
+  if (lane == 0) it = atomicAdd(head, 1);
+  return __builtin_amdgcn_readfirstlane(it);
+}
+
 // ---- DPP wave reductions (no LDS traffic, fixed order => bit-reproducible)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {

@@ -43,6 +43,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   // per-diagonal tables prepared one step ahead by the finalize waves (double-buffered by diagonal parity)
   int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
+  int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
   int split_off[2][NL][2];       // byte offsets of the two operand rows of split point tt
   int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
 };
@@ -216,7 +217,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
       mfe_prepare_tables<NT>(sm, T, d, n, tid, ninio, max_ninio);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
-      if (tid == 0) sm.pcnt[d & 1] = cnt;
+      if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
     }
   }
   __syncthreads();
@@ -274,7 +275,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         mfe_prepare_tables<NT>(sm, T, k + 1, n, tid, ninio, max_ninio);
         const int cnt = PL[(k + 1) * ld + ld - 1];
         if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
-        if (tid == 0) sm.pcnt[(k + 1) & 1] = cnt;
+        if (tid == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
       }
       // exterior column j = k-3 by wave 0: its cells (diagonals <= k-4) were stored in step <= k-3 and
       // drained by the barrier that ended that step
@@ -293,12 +294,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     const bool b_on = lane < 58, o_on = lane < 54;
     const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
     const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
-    const int b_L = T.bulge[b_on ? b_s : 30];
+    const int b_L = keep_i32(T.bulge[b_on ? b_s : 30]);
     const int o_nl = o_s - 1;
-    const int o_L = T.interior[o_on ? o_nl + 1 : 30] + min(max_ninio, (o_nl - 1) * ninio);
-    const int e_bulge1 = T.bulge[1], e_int23 = T.interior[5] + ninio;
-    // K work goes first to the waves whose tower blocks die early (outer blocks)
-    const int krank = NB == 4 ? (aw < 3 ? aw : aw >= 9 ? aw - 6 : aw + 3) : aw;
+    const int o_L = keep_i32(T.interior[o_on ? o_nl + 1 : 30] + min(max_ninio, (o_nl - 1) * ninio));
+    const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -317,67 +316,20 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         STAMP(0);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
         const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
-        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes (two cells per trip)
-        {
-          const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
-          const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-          const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
-          for (int q = aw; q < pcnt; q += 2 * NA) {
-            const bool two = q + NA < pcnt;
-            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + NA : q)];
-            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
-            const int w00 = sm.wring[b_off + i0], w01 = sm.wring[o_off + i0];
-            const int w10 = sm.wring[b_off + i1], w11 = sm.wring[o_off + i1];
-            const int n00 = sm.mm1np[w01 & 127], n10 = sm.mm1np[w11 & 127];
-            const int m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
-            int e00 = (w00 >> 8) + b_L + ((ij0 >> 4) > 2 ? TermAU : 0), e01 = (w01 >> 8) + o_L + n00 + m0;
-            int e10 = (w10 >> 8) + b_L + ((ij1 >> 4) > 2 ? TermAU : 0), e11 = (w11 >> 8) + o_L + n10 + m1;
-            int v0 = min(b_ok ? e00 : INF, o_ok ? e01 : INF);
-            int v1 = min(b_ok ? e10 : INF, o_ok ? e11 : INF);
-            v0 = wave_min_i32_lane63(v0);
-            v1 = wave_min_i32_lane63(v1);
-            if (lane == WAVE - 1) {
-              if (v0 < HALF) atomicMin(&sm.accI[par][i0 + slot0], v0);
-              if (two && v1 < HALF) atomicMin(&sm.accI[par][i1 + slot0], v1);
-            }
-          }
-        }
-        STAMP(1);
-        // ---- X: the nine fixed small shapes, all by one wave per 64 pairable cells (lane = compacted cell)
-        for (int ch = 0; ch * WAVE < pcnt; ch++) {
-          if (aw != NA - 1 - (ch % NA)) continue;
-          const int q = ch * WAVE + lane;
-          const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-          const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-          int w[9];
-#pragma unroll
-          for (int shp = 0; shp < 9; shp++) {
-            const int u1 = (int)((0x322211100ull >> (4 * shp)) & 15ull), u2 = (int)((0x232121010ull >> (4 * shp)) & 15ull);
-            const int dp = d - 2 - u1 - u2;
-            w[shp] = dp > TURN ? sm.wring[(dp & 31) * RS + 1 + u1 + i] : INF * 256;
-          }
-          int e[9];
-          { const int f = w[0] & 127; e[0] = sm.stackp[t * 8 + (f >> 4)]; }
-          { const int f = w[1] & 127; e[1] = e_bulge1 + sm.stackp[t * 8 + (f >> 4)]; }
-          { const int f = w[2] & 127; e[2] = e_bulge1 + sm.stackp[t * 8 + (f >> 4)]; }
-          { const int f = w[3] & 127; e[3] = sm.int11p[(t * 8 + (f >> 4)) * 16 + si1 * 4 + sj1]; }
-          { const int f = w[4] & 127, t2 = f >> 4; e[4] = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((f >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); }
-          { const int f = w[5] & 127, t2 = f >> 4; e[5] = T.int21[(t2 * 8 + t) * 64 + ((f >> 2) & 3) * 16 + si1 * 4 + (f & 3)] - (t2 > 2 ? TermAU : 0); }
-          { const int f = w[6] & 127, t2 = f >> 4; e[6] = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (f & 3) * 16 + ((f >> 2) & 3) * 4 + sj1] - (t2 > 2 ? TermAU : 0); }
-          const int m23 = sm.mm23[cxv];
-          e[7] = e_int23 + m23 + sm.mm23p[w[7] & 127];
-          e[8] = e_int23 + m23 + sm.mm23p[w[8] & 127];
-          int v = INF;
-#pragma unroll
-          for (int shp = 0; shp < 9; shp++) v = min(v, (w[shp] >> 8) + e[shp]);
-          if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
-        }
-        STAMP(2);
-        // ---- K: multiloop splits.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
-        {
-          const int g = lane >> 4, cl = lane & 15;
-          for (int sb = krank; sb * 16 < ncell; sb += NA) {
-            int i = sb * 16 + cl + 1;
+        // ---- floating items of the diagonal, taken from a work queue (LDS counter) so the sweep waves stay
+        // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
+        // pairable cells for the 112 bulge / 1xn shapes (E), then three groups of fixed small shapes per 64
+        // pairable cells (X).  Minima are order-free, so who takes what does not matter.
+        const int nK = (ncell + 15) >> 4, nE = (pcnt + 1) >> 1, nX = 3 * ((pcnt + WAVE - 1) / WAVE);
+        const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
+        const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
+        const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
+        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
+        for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+          if (it < nK) {
+            // ---- K: multiloop splits of 16 cells x 4 split-point groups; lane = cell + 16 g
+            const int g = lane >> 4, cl = lane & 15;
+            int i = it * 16 + cl + 1;
             const bool act = i <= ncell;
             i = act ? i : ncell;
             int acc0 = INF, acc1 = INF;
@@ -393,6 +345,67 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             for (; tt <= d - TURN - 2; tt += 4) acc0 = min(acc0, sm.fml[sm.rowoff[tt] + i - 1] + sm.fml[sm.rowoff[d - tt - 1] + i + tt]);
             acc0 = min(acc0, acc1);
             if (act && acc0 < HALF) atomicMin(&sm.accK[par][i + slot0], acc0);
+          } else if (it < nK + nE) {
+            // ---- E: two pairable cells, the 112 bulge / 1xn shapes over the lanes
+            const int q = 2 * (it - nK);
+            const bool two = q + 1 < pcnt;
+            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
+            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
+            const int w00 = sm.wring[b_off + i0], w01 = sm.wring[o_off + i0];
+            const int w10 = sm.wring[b_off + i1], w11 = sm.wring[o_off + i1];
+            const int n00 = sm.mm1np[w01 & 127], n10 = sm.mm1np[w11 & 127];
+            const int m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+            const int e00 = (w00 >> 8) + b_L + ((ij0 >> 4) > 2 ? TermAU : 0), e01 = (w01 >> 8) + o_L + n00 + m0;
+            const int e10 = (w10 >> 8) + b_L + ((ij1 >> 4) > 2 ? TermAU : 0), e11 = (w11 >> 8) + o_L + n10 + m1;
+            int v0 = min(b_ok ? e00 : INF, o_ok ? e01 : INF);
+            int v1 = min(b_ok ? e10 : INF, o_ok ? e11 : INF);
+            v0 = wave_min_i32_lane63(v0);
+            v1 = wave_min_i32_lane63(v1);
+            if (lane == WAVE - 1) {
+              if (v0 < HALF) atomicMin(&sm.accI[par][i0 + slot0], v0);
+              if (two && v1 < HALF) atomicMin(&sm.accI[par][i1 + slot0], v1);
+            }
+          } else {
+            // ---- X: one group of fixed small shapes for 64 pairable cells (lane = compacted cell)
+            const int xi = it - nK - nE;
+            const int ch = xi / 3, grp = xi - 3 * ch;
+            const int q = ch * WAVE + lane;
+            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+            const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+            int v = INF;
+            if (grp == 0) {
+              // (0,0) (0,1) (1,0) (1,1): LDS tables
+              int w[4];
+#pragma unroll
+              for (int shp = 0; shp < 4; shp++) {
+                const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
+                const int dp = d - 2 - u1 - u2;
+                w[shp] = dp > TURN ? sm.wring[(dp & 31) * RS + 1 + u1 + i] : INF * 256;
+              }
+              const int e0 = sm.stackp[t * 8 + ((w[0] & 127) >> 4)];
+              const int e1 = e_bulge1 + sm.stackp[t * 8 + ((w[1] & 127) >> 4)];
+              const int e2 = e_bulge1 + sm.stackp[t * 8 + ((w[2] & 127) >> 4)];
+              const int e3 = sm.int11p[(t * 8 + ((w[3] & 127) >> 4)) * 16 + si1 * 4 + sj1];
+              v = min(min((w[0] >> 8) + e0, (w[1] >> 8) + e1), min((w[2] >> 8) + e2, (w[3] >> 8) + e3));
+            } else if (grp == 1) {
+              // (1,2) (2,1) (2,2): tables in global memory (L2)
+              const int dpa = d - 5, dpb = d - 6;
+              const int wa = dpa > TURN ? sm.wring[(dpa & 31) * RS + 2 + i] : INF * 256;
+              const int wb = dpa > TURN ? sm.wring[(dpa & 31) * RS + 3 + i] : INF * 256;
+              const int wc = dpb > TURN ? sm.wring[(dpb & 31) * RS + 3 + i] : INF * 256;
+              const int fa = wa & 127, fb = wb & 127, fc = wc & 127;
+              const int ea = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1] - ((fa >> 4) > 2 ? TermAU : 0);
+              const int eb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)] - ((fb >> 4) > 2 ? TermAU : 0);
+              const int ec = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1] - ((fc >> 4) > 2 ? TermAU : 0);
+              v = min((wa >> 8) + ea, min((wb >> 8) + eb, (wc >> 8) + ec));
+            } else {
+              // (2,3) (3,2)
+              const int dp = d - 7;
+              const int wa = dp > TURN ? sm.wring[(dp & 31) * RS + 3 + i] : INF * 256;
+              const int wb = dp > TURN ? sm.wring[(dp & 31) * RS + 4 + i] : INF * 256;
+              v = e_int23 + sm.mm23[cxv] + min((wa >> 8) + sm.mm23p[wa & 127], (wb >> 8) + sm.mm23p[wb & 127]);
+            }
+            if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
           }
         }
         STAMP(5);

@@ -48,6 +48,7 @@ struct PfFastSmem {
   int tw_i[2][32][2];             // per residue: byte offsets A, B into qbi
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
+  int qhead[2];                   // work-queue head of the diagonal's floating items
   unsigned char info[32 * RS];
   unsigned char S[PF_FAST_NMAX + 4];
   int flag;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       pf_prepare_tables<NT>(sm, T, A.scale, d, tid);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
-      if (tid == 0) sm.pcnt[d & 1] = cnt;
+      if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
     }
   }
   __syncthreads();
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         pf_prepare_tables<NT>(sm, T, A.scale, k + 1, tid);
         const int cnt = PL[(k + 1) * ld + ld - 1];
         if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
-        if (tid == 0) sm.pcnt[(k + 1) & 1] = cnt;
+        if (tid == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
       }
       // exterior column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier)
       if (wave == 0 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
@@ -309,13 +310,12 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     const bool b_on = lane < 58, o_on = lane < 54;
     const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
     const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
-    const double b_W = T.bulge[b_s] * A.scale[b_s + 2];
+    const double b_W = keep_f64(T.bulge[b_s] * A.scale[b_s + 2]);
     const int o_nl = o_s - 1;
-    const double o_W = T.interior[o_nl + 1] * T.eninio[o_nl - 1] * A.scale[o_s + 2];
+    const double o_W = keep_f64(T.interior[o_nl + 1] * T.eninio[o_nl - 1] * A.scale[o_s + 2]);
     // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
-    const double x_b1 = T.bulge[1] * A.scale[3], x_23 = T.interior[5] * T.eninio[1] * A.scale[7];
-    const double sc4 = A.scale[4], sc5 = A.scale[5], sc6 = A.scale[6];
-    const int krank = NB == 4 ? (aw < 3 ? aw : aw >= 9 ? aw - 6 : aw + 3) : aw;   // K work first to waves whose towers die early
+    const double x_b1 = keep_f64(T.bulge[1] * A.scale[3]), x_23 = keep_f64(T.interior[5] * T.eninio[1] * A.scale[7]);
+    const double sc4 = keep_f64(A.scale[4]), sc5 = keep_f64(A.scale[5]), sc6 = keep_f64(A.scale[6]);
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -332,14 +332,36 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
         }
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
-        // ---- E: bulges and 1xn loops, one pairable cell per pass, shapes over the lanes (two cells per trip)
-        {
-          const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
-          const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-          const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
-          for (int q = aw; q < pcnt; q += 2 * NA) {
-            const bool two = q + NA < pcnt;
-            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + NA : q)];
+        // ---- floating items of the diagonal, taken from a work queue (LDS counter): 16-cell multiloop
+        // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
+        // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
+        // not depend on which wave takes it.
+        const int nK = (ncell + 15) >> 4, nE = (pcnt + 1) >> 1, nX = 3 * ((pcnt + WAVE - 1) / WAVE);
+        const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
+        const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
+        const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
+        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
+        for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+          if (it < nK) {
+            const int g = lane >> 4, cl = lane & 15;
+            int i = it * 16 + cl + 1;
+            const bool act = i <= ncell;
+            i = act ? i : ncell;
+            double acc0 = 0.0, acc1 = 0.0;
+            int tt = TURN + 1 + g;
+            for (; tt + 12 <= d - TURN - 2; tt += 16) {
+              const double a0 = QM[tt * ld + i], c0 = QM1[(d - tt - 1) * ld + i + tt + 1];
+              const double a1 = QM[(tt + 4) * ld + i], c1 = QM1[(d - tt - 5) * ld + i + tt + 5];
+              const double a2 = QM[(tt + 8) * ld + i], c2 = QM1[(d - tt - 9) * ld + i + tt + 9];
+              const double a3 = QM[(tt + 12) * ld + i], c3 = QM1[(d - tt - 13) * ld + i + tt + 13];
+              acc0 += a0 * c0; acc1 += a1 * c1; acc0 += a2 * c2; acc1 += a3 * c3;
+            }
+            for (; tt <= d - TURN - 2; tt += 4) acc0 += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
+            if (act) sm.partK[par][g][i + slot0] = acc0 + acc1;
+          } else if (it < nK + nE) {
+            const int q = 2 * (it - nK);
+            const bool two = q + 1 < pcnt;
+            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
             const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
             const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
             const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
@@ -355,70 +377,47 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
               sm.accE[par][i0 + slot0] = v0;
               if (two) sm.accE[par][i1 + slot0] = v1;
             }
-          }
-        }
-        // ---- X: the nine fixed small shapes in three groups (one sum slice each), a group per wave and per
-        // 64 pairable cells (lane = compacted cell); groups go to the last sweep waves, whose towers die early
-        for (int it = 0; it < 3 * ((pcnt + WAVE - 1) / WAVE); it++) {
-          const int ch = it / 3, grp = it - 3 * ch;
-          if (aw != NA - 1 - (it % NA)) continue;
-          const int q = ch * WAVE + lane;
-          const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-          const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-          double sum;
-          if (grp == 0) {
-            // (0,0) (0,1) (1,0) (1,1): LDS tables
-            double w[4];
-            int f[4];
-#pragma unroll
-            for (int shp = 0; shp < 4; shp++) {
-              const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
-              const int dp = d - 2 - u1 - u2;
-              const int off = (dp & 31) * RS + 1 + u1 + i;
-              w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
-              f[shp] = dp > TURN ? sm.info[off] : 0;
-            }
-            sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
-            sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * x_b1;
-            sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sc4;
-          } else if (grp == 1) {
-            // (1,2) (2,1) (2,2): tables in global memory (L2)
-            const int dpa = d - 5, dpb = d - 6;
-            const int oa = (dpa & 31) * RS + 2 + i, ob = (dpa & 31) * RS + 3 + i, oc = (dpb & 31) * RS + 3 + i;
-            const double wa = dpa > TURN ? sm.qbi[oa] : 0.0, wb = dpa > TURN ? sm.qbi[ob] : 0.0, wc = dpb > TURN ? sm.qbi[oc] : 0.0;
-            const int fa = dpa > TURN ? sm.info[oa] : 0, fb = dpa > TURN ? sm.info[ob] : 0, fc = dpb > TURN ? sm.info[oc] : 0;
-            const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
-            const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
-            const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
-            sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sc5 + wc * sm.rinv[fc] * gc * sc6;
           } else {
-            // (2,3) (3,2)
-            const int dp = d - 7;
-            const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
-            const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
-            const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
-            sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * x_23;
-          }
-          if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
-        }
-        // ---- K: multiloop sums from L2.  16 cells x 4 split-point groups per wave; lane = cell + 16 g
-        {
-          const int g = lane >> 4, cl = lane & 15;
-          for (int sb = krank; sb * 16 < ncell; sb += NA) {
-            int i = sb * 16 + cl + 1;
-            const bool act = i <= ncell;
-            i = act ? i : ncell;
-            double acc0 = 0.0, acc1 = 0.0;
-            int tt = TURN + 1 + g;
-            for (; tt + 12 <= d - TURN - 2; tt += 16) {
-              const double a0 = QM[tt * ld + i], c0 = QM1[(d - tt - 1) * ld + i + tt + 1];
-              const double a1 = QM[(tt + 4) * ld + i], c1 = QM1[(d - tt - 5) * ld + i + tt + 5];
-              const double a2 = QM[(tt + 8) * ld + i], c2 = QM1[(d - tt - 9) * ld + i + tt + 9];
-              const double a3 = QM[(tt + 12) * ld + i], c3 = QM1[(d - tt - 13) * ld + i + tt + 13];
-              acc0 += a0 * c0; acc1 += a1 * c1; acc0 += a2 * c2; acc1 += a3 * c3;
+            const int xi = it - nK - nE;
+            const int ch = xi / 3, grp = xi - 3 * ch;
+            const int q = ch * WAVE + lane;
+            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+            const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+            double sum;
+            if (grp == 0) {
+              // (0,0) (0,1) (1,0) (1,1): LDS tables
+              double w[4];
+              int f[4];
+#pragma unroll
+              for (int shp = 0; shp < 4; shp++) {
+                const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
+                const int dp = d - 2 - u1 - u2;
+                const int off = (dp & 31) * RS + 1 + u1 + i;
+                w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
+                f[shp] = dp > TURN ? sm.info[off] : 0;
+              }
+              sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
+              sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * x_b1;
+              sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sc4;
+            } else if (grp == 1) {
+              // (1,2) (2,1) (2,2): tables in global memory (L2)
+              const int dpa = d - 5, dpb = d - 6;
+              const int oa = (dpa & 31) * RS + 2 + i, ob = (dpa & 31) * RS + 3 + i, oc = (dpb & 31) * RS + 3 + i;
+              const double wa = dpa > TURN ? sm.qbi[oa] : 0.0, wb = dpa > TURN ? sm.qbi[ob] : 0.0, wc = dpb > TURN ? sm.qbi[oc] : 0.0;
+              const int fa = dpa > TURN ? sm.info[oa] : 0, fb = dpa > TURN ? sm.info[ob] : 0, fc = dpb > TURN ? sm.info[oc] : 0;
+              const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
+              const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
+              const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
+              sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sc5 + wc * sm.rinv[fc] * gc * sc6;
+            } else {
+              // (2,3) (3,2)
+              const int dp = d - 7;
+              const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
+              const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
+              const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
+              sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * x_23;
             }
-            for (; tt <= d - TURN - 2; tt += 4) acc0 += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
-            if (act) sm.partK[par][g][i + slot0] = acc0 + acc1;
+            if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
           }
         }
       }

@@ -67,7 +67,7 @@ static inline unsigned long long __ballot(bool p) {
 }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
-static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+static inline int __builtin_amdgcn_readfirstlane(int x) { return emu_exchange(x, 0); }   // all lanes of the wave are active wherever the kernels use it
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_exchange(v, lane); }
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   (void)bank_mask;
@@ -94,6 +94,7 @@ static inline int atomicMin(int* p, int v) {
   while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 using std::min;
 using std::max;
 
