@@ -7,16 +7,16 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 STEPS=${STEPS:-50}
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-echo "== bench"; timeout 900 python bench.py --steps $STEPS --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; cat gpurun_out/bench.json
-echo "== bench design-like"; timeout 600 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline > gpurun_out/bench_design.json 2>/dev/null; cat gpurun_out/bench_design.json
+echo "== pytest gpu"; timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+echo "== bench"; timeout 300 python bench.py --steps $STEPS --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; cat gpurun_out/bench.json
+echo "== bench design-like"; timeout 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline > gpurun_out/bench_design.json 2>/dev/null; cat gpurun_out/bench_design.json
 echo "== rocprof kernel trace"
-rm -rf gpurun_out/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps $STEPS --warmup 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/bench_prof.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof.err")
+rm -rf gpurun_out/prof; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps $STEPS --warmup 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/bench_prof.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof.err")
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv"); do cat $f; done
 echo "== PMC: HBM traffic"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -o $c -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.err")
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -o $c -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.err")
 done
 python3 - <<'PY'
 import csv, glob, json, collections
