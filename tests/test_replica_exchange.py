@@ -88,3 +88,45 @@ def test_sharded_allgather_and_identical_swaps_gloo_world2(tmp_path):
     for o in outs:
         assert np.array_equal(np.array(o["full"]), truth)
     assert outs[0]["temps"] == outs[1]["temps"]
+
+
+def test_sharded_design_run_gloo_world2(tmp_path):
+    """The whole design loop with replicas sharded over two ranks (gloo, oracle-backed scorer): both ranks must
+    agree on the temperature ladder after every exchange and together hold every replica exactly once."""
+    script = tmp_path / "worker_design.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from types import SimpleNamespace
+        import torch.distributed as dist
+        from desirna_amd import design, params
+        from desirna_amd.energy_scores import parse_scoring_functions
+        from desirna_amd.replica_exchange import ReplicaShards
+        from oracle.pyoracle import Oracle
+        from tests.test_design_driver import OracleScorer, ETE1
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        inp = SimpleNamespace(name="e1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+        sc = OracleScorer(Oracle(params.load_blob()), ETE1, parse_scoring_functions("Ed-Epf:1.0"))
+        res = design.run_design(inp, replicas=6, exchange=10, steps=3, seed=11, scorer=sc, shards=ReplicaShards(6, rank, world))
+        print(json.dumps({"rank": rank, "reps": [s.replica_num for s in res["replicas"]],
+                          "temps": [s.temp_shelf for s in res["replicas"]], "scored": res["stats"]["scored"],
+                          "acc_re": res["stats"]["acc_re"], "rej_re": res["stats"]["rej_re"]}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    port = _free_port()
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    import json
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    assert sorted(outs[0]["reps"] + outs[1]["reps"]) == [1, 2, 3, 4, 5, 6]
+    from desirna_amd.replica_exchange import get_rep_temps
+    assert sorted(outs[0]["temps"] + outs[1]["temps"]) == sorted(get_rep_temps(6, 10.0, 150.0))
+    assert (outs[0]["acc_re"], outs[0]["rej_re"]) == (outs[1]["acc_re"], outs[1]["rej_re"])   # same swap decisions
+    assert outs[0]["scored"] == outs[1]["scored"] == 3 + 3 * 10 * 3
