@@ -16,6 +16,7 @@
 #include "eval_structure.hpp"
 #include "fold_mfe.hpp"
 #include "fold_mfe_lds.hpp"
+#include "fold_outside.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
 #include "host_driver.hpp"
@@ -52,6 +53,11 @@ struct drna_engine {
   hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_m0 = nullptr, ev_m1 = nullptr, ev_p0 = nullptr,
              ev_p1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
   float timing[4] = {0, 0, 0, 0};
+  // ensemble defect (outside recursion): workspace allocated on first use
+  double* d_ws_out = nullptr;
+  double* d_edef = nullptr;
+  hipEvent_t ev_o0 = nullptr, ev_o1 = nullptr, ev_o2 = nullptr;
+  float timing_edef[2] = {0, 0};
   std::string err;
 };
 
@@ -116,7 +122,8 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipStreamCreateWithFlags(&e->s_mfe, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_pf, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_eval, hipStreamNonBlocking));
-  hipEvent_t* evs[] = {&e->ev_start, &e->ev_end, &e->ev_m0, &e->ev_m1, &e->ev_p0, &e->ev_p1, &e->ev_e0, &e->ev_e1};
+  hipEvent_t* evs[] = {&e->ev_start, &e->ev_end, &e->ev_m0, &e->ev_m1, &e->ev_p0, &e->ev_p1, &e->ev_e0, &e->ev_e1,
+                       &e->ev_o0, &e->ev_o1, &e->ev_o2};
   for (hipEvent_t* ev : evs) HIP_TRY(hipEventCreate(ev));
   return DRNA_OK;
 }
@@ -138,14 +145,16 @@ extern "C" int drna_create(const int32_t* params, int n_int32, int device, int m
 extern "C" void drna_destroy(drna_engine* e) {
   if (!e) return;
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
-                  e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt};
+                  e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
+                  e->d_ws_out, e->d_edef};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
   hipStream_t ss[] = {e->s_mfe, e->s_pf, e->s_eval};
   for (hipStream_t s : ss)
     if (s) (void)hipStreamDestroy(s);
-  hipEvent_t evs[] = {e->ev_start, e->ev_end, e->ev_m0, e->ev_m1, e->ev_p0, e->ev_p1, e->ev_e0, e->ev_e1};
+  hipEvent_t evs[] = {e->ev_start, e->ev_end, e->ev_m0, e->ev_m1, e->ev_p0, e->ev_p1, e->ev_e0, e->ev_e1,
+                      e->ev_o0, e->ev_o1, e->ev_o2};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   delete e;
@@ -317,6 +326,107 @@ extern "C" int drna_last_timing(const drna_engine* e, float out[4]) {
 extern "C" int drna_info(const drna_engine* e, int64_t out[6]) {
   if (!e || !out) return DRNA_ERR_ARG;
   out[0] = e->device; out[1] = e->max_R; out[2] = e->max_L; out[3] = e->nt; out[4] = e->cus; out[5] = (int64_t)e->ws_bytes;
+  return DRNA_OK;
+}
+
+// ---------------------------------------------------------------- ensemble defect (inside + outside recursion)
+
+template <int NT>
+static void launch_outside(const OutArgs& a, int R, hipStream_t s) {
+  hipLaunchKernelGGL(outside_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+
+extern "C" int drna_ensemble_defect_batch_device(drna_engine* e, int R, int L, const char* d_seqs, double* d_edef,
+                                                 double* d_bpp) {
+  if (!e) return DRNA_ERR_ARG;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || !d_seqs || !d_edef) {
+    e->err = "drna_ensemble_defect_batch: bad argument (R, L within the engine's limits; seqs and edef required)";
+    return DRNA_ERR_ARG;
+  }
+  if (e->n_targets < 1 || e->L_targets != L) {
+    e->err = "drna_ensemble_defect_batch: needs drna_set_targets() with the same L (targets[0] is the reference structure)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const int ldmax = e->max_L + 2, ld = L + 2;
+  if (!e->d_ws_out) {
+    HIP_TRY(hipMalloc((void**)&e->d_ws_out, (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->max_R));
+    e->ws_bytes += (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->max_R;
+  }
+  for (int k = 0; k < R; k++) e->h_status[e->max_R + k] = ST_OK;
+  // the general inside kernel: it leaves qb / qm / qm1 in the workspace (the LDS kernel keeps only rings)
+  PfArgs a;
+  a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
+  a.seqs = d_seqs; a.L = L; a.ld = ld;
+  a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
+  a.Epf = e->d_Epf; a.status = e->d_status + e->max_R;
+  a.q5_stride = outside_ws_stride(ld);
+  a.q5out = e->d_ws_out + (size_t)4 * ld * ld;
+  OutArgs o;
+  o.T = e->d_pfT; o.plan = e->d_plan; o.scale = e->d_scale; o.eMLb = e->d_eMLb;
+  o.seqs = d_seqs; o.L = L; o.ld = ld;
+  o.ws = e->d_ws_pf; o.ws_stride = a.ws_stride;
+  o.wo = e->d_ws_out; o.wo_stride = outside_ws_stride(ld);
+  o.pt = e->d_pt; o.edef = d_edef; o.bpp = d_bpp; o.pf_status = e->d_status + e->max_R;
+  HIP_TRY(hipEventRecord(e->ev_o0, e->s_pf));
+  if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
+  else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
+  else launch_pf<1024>(a, R, e->s_pf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev_o1, e->s_pf));
+  if (e->nt == 256) launch_outside<256>(o, R, e->s_pf);
+  else if (e->nt == 512) launch_outside<512>(o, R, e->s_pf);
+  else launch_outside<1024>(o, R, e->s_pf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev_o2, e->s_pf));
+  HIP_TRY(hipStreamSynchronize(e->s_pf));
+  HIP_TRY(hipEventElapsedTime(&e->timing_edef[0], e->ev_o0, e->ev_o1));
+  HIP_TRY(hipEventElapsedTime(&e->timing_edef[1], e->ev_o1, e->ev_o2));
+  for (int r = 0; r < R; r++) {
+    const int st = e->h_status[e->max_R + r];
+    if (st == ST_OK) continue;
+    char buf[160];
+    if (st == ST_BAD_CHAR) {
+      snprintf(buf, sizeof buf, "sequence %d holds a character other than A C G U T", r);
+      e->err = buf;
+      return DRNA_ERR_SEQUENCE;
+    }
+    snprintf(buf, sizeof buf, "sequence %d: partition function left the fp64 range (pf_scale too small/large)", r);
+    e->err = buf;
+    return DRNA_ERR_PF_RANGE;
+  }
+  return DRNA_OK;
+}
+
+extern "C" int drna_ensemble_defect_batch(drna_engine* e, int R, int L, const char* seqs, double* edef, double* bpp) {
+  if (!e) return DRNA_ERR_ARG;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || !seqs || !edef) {
+    e->err = "drna_ensemble_defect_batch: bad argument (R, L within the engine's limits; seqs and edef required)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_edef) HIP_TRY(hipMalloc((void**)&e->d_edef, (size_t)e->max_R * sizeof(double)));
+  HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
+  double* d_bpp = nullptr;
+  const size_t nb = (size_t)R * (L + 1) * (L + 1) * sizeof(double);
+  if (bpp) {
+    HIP_TRY(hipMalloc((void**)&d_bpp, nb));
+    hipError_t z = hipMemset(d_bpp, 0, nb);
+    if (z != hipSuccess) { (void)hipFree(d_bpp); e->err = "hipMemset(bpp)"; return DRNA_ERR_DEVICE; }
+  }
+  int rc = drna_ensemble_defect_batch_device(e, R, L, e->d_seqs, e->d_edef, d_bpp);
+  if (rc == DRNA_OK) {
+    hipError_t c1 = hipMemcpy(edef, e->d_edef, (size_t)R * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t c2 = bpp ? hipMemcpy(bpp, d_bpp, nb, hipMemcpyDeviceToHost) : hipSuccess;
+    if (c1 != hipSuccess || c2 != hipSuccess) { e->err = "hipMemcpy(edef/bpp)"; rc = DRNA_ERR_DEVICE; }
+  }
+  if (d_bpp) (void)hipFree(d_bpp);
+  return rc;
+}
+
+extern "C" int drna_last_edef_timing(const drna_engine* e, float out[2]) {
+  if (!e || !out) return DRNA_ERR_ARG;
+  out[0] = e->timing_edef[0]; out[1] = e->timing_edef[1];
   return DRNA_OK;
 }
 

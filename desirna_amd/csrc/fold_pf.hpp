@@ -28,6 +28,8 @@ struct PfArgs {
   long long ws_stride;         // doubles per sequence
   double* Epf;                 // R  (kcal/mol)
   int32_t* status;             // R
+  double* q5out = nullptr;     // optional: q5[0..L] per sequence for the outside recursion (fold_outside.hpp)
+  long long q5_stride = 0;     // doubles per sequence
 };
 
 struct PfSmem {
@@ -233,6 +235,8 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
       s = wave_sum_f64(s);
       sm.q5[j] = sm.q5[j - 1] * sc1 + s;    // every lane stores the same value
     }
+    if (A.q5out)
+      for (int j = lane; j <= n; j += WAVE) A.q5out[(long long)r * A.q5_stride + j] = sm.q5[j];
     if (lane == 0) {
       const double Z = sm.q5[n];
       if (!(Z > 0.0) || !(Z < 1.0e300)) {

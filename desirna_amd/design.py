@@ -246,8 +246,6 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     for name, _ in sf:
         if name not in es.AVAILABLE_SCORING_FUNCTIONS:
             raise ValueError("%s is not an available option for scoring function. Check your command." % name)
-        if name == "Edef":
-            raise NotImplementedError("Edef (ensemble defect) needs the outside recursion: not on the GPU path yet")
     R, L = replicas, prob.n
     eng = engine or _engine.Engine(max_R=R, max_L=L, device=device)
     hk = _engine.HostKernels()
@@ -279,6 +277,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
                 total += (1 - prec) * 10 * w
             elif name == "1-recall":
                 total += (1 - rec) * 10 * w
+            elif name == "Edef":
+                total += eng.ensemble_defect_arrays(seqs_u8) * w
         return total, 1 - mcc, ss, Epf, ed
 
     init = prob.initial_sequence(main_rng)

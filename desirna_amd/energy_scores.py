@@ -9,6 +9,8 @@ motif bonus (:121-123, :443-450).  What changes is where the numbers come from: 
 E(target), E(alt targets) for every replica of the batch, instead of 3-8 ViennaRNA calls per
 sequence inside a forked worker.
 
+``Edef`` is served by ``Engine.ensemble_defect`` (inside + outside recursion on the GPU).
+
 Out of scope here: two-strand inputs (``oligo_state`` homodimer / heterodimer /
 avoid) and ``-nd on`` sub-optimal search -- they raise NotImplementedError rather than silently
 giving different numbers.
@@ -108,6 +110,12 @@ class ScoreSeq:
     def get_edesired_minus_MFE(self):
         self.edesired_minus_MFE = self.edesired - self.MFE
 
+    def get_ensemble_defect(self, ensemble_defect):
+        """reference :362-374 runs mfe / rescale / pf / ensemble_defect on a new fold compound; here the value
+        comes from the engine's inside + outside kernels (Engine.ensemble_defect).  The attribute is created on
+        first use exactly as in the reference (it is not part of __init__ there either)."""
+        self.ensemble_defect = ensemble_defect
+
     def get_scoring_function(self, scoring_f):
         self.scoring_function = 0
         for function, weight in scoring_f:
@@ -167,14 +175,15 @@ class ReplicaScorer:
         for function, _ in sim_options.scoring_f:
             if function not in AVAILABLE_SCORING_FUNCTIONS:
                 raise ValueError("%s is not an available option for scoring function. Check your command." % function)
-            if function == 'Edef':
-                raise NotImplementedError("Edef (ensemble defect) needs the outside recursion: not on the GPU path yet")
+        # reference :93-94: get_ensemble_defect(input_file.sec_struct) whenever 'Edef' is among the -sf terms
+        self.want_edef = any(function == 'Edef' for function, _ in sim_options.scoring_f)
 
     def score(self, seqs):
         """list of sequences -> list of ScoreSeq (reference score_sequence(), once per replica)."""
         out = self.engine.score_batch(list(seqs), self.flags)
         metrics = batch_metrics(self.input_file.sec_struct.replace("&", "Ee"),
                                 [s.replace("&", "Ee") for s in out["mfe_ss"]])
+        edef = self.engine.ensemble_defect(list(seqs)) if self.want_edef else None
         res = []
         for k, seq in enumerate(seqs):
             sc = ScoreSeq(sequence=seq)
@@ -192,6 +201,8 @@ class ReplicaScorer:
                 if function == 'Ed-MFE':
                     sc.get_MFE(int(out["Emfe"][k]) / 100.0)
                     sc.get_edesired_minus_MFE()
+                if function == 'Edef':
+                    sc.get_ensemble_defect(float(edef[k]))
             sc.get_scoring_function(self.sim_options.scoring_f)
             if getattr(self.input_file, "alt_sec_struct", None) is not None:
                 energies = [int(e) / 100.0 for e in out["Ed"][k, 1:]]

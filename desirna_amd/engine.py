@@ -23,7 +23,8 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
-           "drna_metropolis_batch")
+           "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
+           "drna_last_edef_timing")
 
 
 class EngineError(RuntimeError):
@@ -57,6 +58,12 @@ def load_library(path=None):
     L.drna_last_timing.argtypes = [vp, vp]
     L.drna_info.restype = ci
     L.drna_info.argtypes = [vp, vp]
+    L.drna_ensemble_defect_batch.restype = ci
+    L.drna_ensemble_defect_batch.argtypes = [vp, ci, ci, C.c_char_p, vp, vp]
+    L.drna_ensemble_defect_batch_device.restype = ci
+    L.drna_ensemble_defect_batch_device.argtypes = [vp, ci, ci, vp, vp, vp]
+    L.drna_last_edef_timing.restype = ci
+    L.drna_last_edef_timing.argtypes = [vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -141,6 +148,34 @@ class Engine:
         The caller must have made the inputs visible (``torch.cuda.synchronize()``) before the call."""
         self._check(self._L.drna_score_batch_device(self._h, R, L, d_seqs, flags, d_Epf, d_Emfe, d_ss, d_Ed))
 
+    def ensemble_defect(self, seqs, want_bpp=False):
+        """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
+        utils/energy_scores.py:362-374).  Returns float64[R]; with want_bpp also the (R, L+1, L+1) base-pair
+        probability matrices (1-based, upper triangle)."""
+        R = len(seqs)
+        L = len(seqs[0])
+        if any(len(s) != L for s in seqs):
+            raise ValueError("all sequences of a batch must have the same length")
+        ed = np.zeros(R, dtype=np.float64)
+        bpp = np.zeros((R, L + 1, L + 1), dtype=np.float64) if want_bpp else None
+        self._check(self._L.drna_ensemble_defect_batch(self._h, R, L, "".join(seqs).encode("ascii"), ed.ctypes.data,
+                                                       bpp.ctypes.data if want_bpp else None))
+        return (ed, bpp) if want_bpp else ed
+
+    def ensemble_defect_arrays(self, seqs_u8):
+        """Array form of :meth:`ensemble_defect`: (R, L) uint8 ASCII letters -> float64[R]."""
+        seqs_u8 = np.ascontiguousarray(seqs_u8, dtype=np.uint8)
+        R, L = seqs_u8.shape
+        ed = np.zeros(R, dtype=np.float64)
+        self._check(self._L.drna_ensemble_defect_batch(self._h, R, L, seqs_u8.ctypes.data_as(C.c_char_p),
+                                                       ed.ctypes.data, None))
+        return ed
+
+    def last_edef_timing(self):
+        out = (C.c_float * 2)()
+        self._check(self._L.drna_last_edef_timing(self._h, out))
+        return {"inside": out[0], "outside": out[1]}
+
     def last_timing(self):
         """ms of device time of the last call: dict(mfe, pf, eval, total) from HIP events on the engine's streams."""
         out = (C.c_float * 4)()
@@ -197,5 +232,6 @@ class HostKernels:
         rc = self._L.drna_metropolis_batch(R, so.ctypes.data, sm.ctypes.data, tt.ctypes.data, float(L_const),
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
-            raise EngineError(rc, "drna_metropolis_batch")
+            raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
+           "drna_last_edef_timing")
         return acc.astype(bool), bet.astype(bool)

@@ -96,6 +96,25 @@ int drna_score_batch_device(drna_engine *e, int R, int L, const char *d_seqs, ui
  */
 int drna_last_timing(const drna_engine *e, float out[4]);
 
+/*
+ * Ensemble defect of R sequences against targets[0] (needs drna_set_targets with the same L): inside fill,
+ * outside recursion, base-pair probabilities, then (1/L) * [ sum_{i unpaired in target} sum_j P(i,j)
+ * + sum_{i paired with m in target} (1 - P(i,m)) ], '(' ')' pairs only.
+ * Replaces ScoreSeq.get_ensemble_defect (energy_scores.py:362-374: new fold compound with bpp on, fc.mfe(),
+ * fc.exp_params_rescale(mfe), fc.pf(), fc.ensemble_defect(target)); the rescale only moves pf_scale, which
+ * cancels in every probability.
+ *   edef  R doubles in [0,1]                                     out
+ *   bpp   R*(L+1)*(L+1) doubles, P(i,j) at [r][i][j], 1 <= i < j <= L  out, may be NULL
+ */
+int drna_ensemble_defect_batch(drna_engine *e, int R, int L, const char *seqs, double *edef, double *bpp);
+
+/* Same with device-resident buffers; d_bpp (may be NULL) must be zero-filled by the caller. */
+int drna_ensemble_defect_batch_device(drna_engine *e, int R, int L, const char *d_seqs, double *d_edef,
+                                      double *d_bpp);
+
+/* device ms of the last drna_ensemble_defect_batch*: out[0] = inside kernel, out[1] = outside kernel */
+int drna_last_edef_timing(const drna_engine *e, float out[2]);
+
 /* engine facts: out[0]=device, out[1]=max_R, out[2]=max_L, out[3]=threads per workgroup,
  * out[4]=compute units, out[5]=bytes of device workspace */
 int drna_info(const drna_engine *e, int64_t out[6]);

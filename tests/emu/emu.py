@@ -21,6 +21,7 @@ def build():
     L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
+    L.emu_edef.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, ci, vp, vp, vp]
     return L
 
 
@@ -71,3 +72,23 @@ class Emu:
                              pt.ctypes.data, Ed.ctypes.data)
         assert rc == 0
         return Ed
+
+    def edef(self, seqs, target, nt=128, bpp=False):
+        """general pf_kernel + outside_kernel: ensemble defect against `target` (and the bpp matrices)"""
+        R, L = len(seqs), len(seqs[0])
+        pt = np.zeros(L + 2, dtype=np.int16)
+        stk = []
+        for i, ch in enumerate(target, 1):
+            if ch == "(":
+                stk.append(i)
+            elif ch == ")":
+                o = stk.pop()
+                pt[o] = i
+                pt[i] = o
+        ed = np.zeros(R)
+        st = np.zeros(R, dtype=np.int32)
+        B = np.zeros((R, L + 1, L + 1)) if bpp else None
+        rc = self.L.emu_edef(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), pt.ctypes.data, nt,
+                             ed.ctypes.data, B.ctypes.data if bpp else None, st.ctypes.data)
+        assert rc == 0
+        return (ed, st, B) if bpp else (ed, st)

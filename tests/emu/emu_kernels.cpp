@@ -11,6 +11,7 @@ emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_mfe_lds.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
+#include "../../desirna_amd/csrc/fold_outside.hpp"
 
 using namespace drna;
 
@@ -90,6 +91,44 @@ int emu_eval(const int32_t* blob, int n_int32, int R, int L, const char* seqs, i
   a.T = &c->H.mfe; a.hp_len = c->H.hp_len.data(); a.bulge_len = c->H.bulge_len.data(); a.int_len = c->H.int_len.data();
   a.seqs = seqs; a.pt = pt; a.L = L; a.n_targets = n_targets; a.Ed = Ed;
   for (int b = 0; b < R * n_targets; b++) emu_launch(b, 64, [&]() { eval_kernel(a); });
+  delete c;
+  return 0;
+}
+
+// general pf_kernel followed by outside_kernel; pt = pair table of the target (L+2 shorts); bpp optional R*(L+1)*(L+1)
+int emu_edef(const int32_t* blob, int n_int32, int R, int L, const char* seqs, const short* pt, int nt, double* edef,
+             double* bpp, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  const size_t stride = (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8;
+  const size_t ostride = (size_t)outside_ws_stride(ld);
+  std::vector<double> ws(stride, 0.0), wo(ostride, 0.0), Epf(R, 0.0);
+  for (int r = 0; r < R; r++) {
+    PfArgs a;
+    a.T = &c->H.pf; a.plan = &c->H.plan; a.hp_w = c->H.hp_w.data(); a.scale = c->H.scale.data();
+    a.eMLb = c->H.eMLb.data(); a.seqs = seqs; a.L = L; a.ld = ld;
+    a.ws = ws.data() - (size_t)r * stride; a.ws_stride = (long long)stride;
+    a.Epf = Epf.data(); a.status = status;
+    a.q5out = wo.data() + (size_t)4 * ld * ld - (size_t)r * ostride; a.q5_stride = (long long)ostride;
+    OutArgs o;
+    o.T = &c->H.pf; o.plan = &c->H.plan; o.scale = c->H.scale.data(); o.eMLb = c->H.eMLb.data();
+    o.seqs = seqs; o.L = L; o.ld = ld; o.ws = a.ws; o.ws_stride = a.ws_stride;
+    o.wo = wo.data() - (size_t)r * ostride; o.wo_stride = (long long)ostride;
+    o.pt = pt; o.edef = edef; o.bpp = bpp; o.pf_status = status;
+    auto f1 = [&]() {
+      if (nt == 64) pf_kernel<64>(a);
+      else if (nt == 128) pf_kernel<128>(a);
+      else pf_kernel<256>(a);
+    };
+    auto f2 = [&]() {
+      if (nt == 64) outside_kernel<64>(o);
+      else if (nt == 128) outside_kernel<128>(o);
+      else outside_kernel<256>(o);
+    };
+    emu_launch(r, nt, f1);
+    emu_launch(r, nt, f2);
+  }
   delete c;
   return 0;
 }

@@ -174,3 +174,56 @@ def test_replica_scorer_matches_reference_fields(traj_golden, example_inputs):
         assert abs(s.Epf - float(r["Epf"])) < EPF_TOL_GOLDEN
         assert abs(s.edesired - float(r["edesired"])) < 1e-6
         assert abs(s.scoring_function - (s.edesired - s.Epf)) < 1e-12
+
+
+# ---- ensemble defect: inside + outside recursion on the GPU against the oracle.  The reference
+# holds no golden for this quantity, so the oracle itself is pinned by exhaustive enumeration on short
+# sequences (tests/test_oracle_golden.py) -- "parity unpinned" against the reference for Edef.
+EDEF_TOL = 1e-10
+
+
+@pytest.mark.parametrize("L", [1, 4, 5, 9, 36, 100, 200])
+def test_ensemble_defect_vs_oracle(eng400, oracle, L):
+    rng = np.random.default_rng(900 + L)
+    seqs = [_rand(rng, L) for _ in range(5)] + [_rand(rng, L, "GC")]
+    target = oracle.mfe(seqs[0])[0]
+    eng400.set_targets([target])
+    ed, bpp = eng400.ensemble_defect(seqs, want_bpp=True)
+    for k, s in enumerate(seqs):
+        oe, ob = oracle.ensemble_defect(s, target, want_bpp=True)
+        assert abs(ed[k] - oe) < EDEF_TOL, (s, ed[k], oe)
+        assert np.abs(bpp[k] - ob).max() < EDEF_TOL, s
+    # bitwise repeatability and independence of batch composition
+    ed2 = eng400.ensemble_defect(seqs[::-1])
+    assert np.array_equal(ed2[::-1], ed)
+
+
+def test_ensemble_defect_config5_shape(eng400, oracle, eterna_targets):
+    """BASELINE config 5 shape: L=400 target, full-width batch; probabilities are a distribution per base."""
+    target = eterna_targets["eteV1_53.txt"]
+    assert len(target) == 400
+    rng = np.random.default_rng(4005)
+    seqs = [_rand(rng, 400) for _ in range(8)]
+    eng400.set_targets([target])
+    ed, bpp = eng400.ensemble_defect(seqs, want_bpp=True)
+    for k in range(2):
+        oe = oracle.ensemble_defect(seqs[k], target)
+        assert abs(ed[k] - oe) < EDEF_TOL
+    P = bpp + bpp.transpose(0, 2, 1)
+    assert (P.sum(axis=2) <= 1.0 + 1e-9).all() and (bpp >= 0).all()
+    assert ((0 <= ed) & (ed <= 1)).all()
+
+
+def test_edef_scoring_function(eng400, oracle):
+    """-sf Edef:1.0 through ReplicaScorer (reference energy_scores.py:93-94, :397-398)."""
+    from types import SimpleNamespace
+    from desirna_amd.energy_scores import ReplicaScorer
+    target = "((((((.((((((((....))))).)).).))))))"
+    inp = SimpleNamespace(sec_struct=target, alt_sec_struct=None, alt_sec_structs=None)
+    opts = SimpleNamespace(oligo_state="none", subopt="off", pks="off", scoring_f=[("Edef", 1.0)], motifs={}, param="1999")
+    sc = ReplicaScorer(inp, opts, max_replicas=4, engine=eng400)
+    seqs = ["GGUGACACCGACGGCUACUGCCGUACGUGCGUCACC", "CGCGGGAGGGGGCCGGAAACGGCCACCACACCCGCG"]
+    res = sc.score(seqs)
+    for s, r in zip(seqs, res):
+        assert abs(r.ensemble_defect - oracle.ensemble_defect(s, target)) < EDEF_TOL
+        assert r.scoring_function == r.ensemble_defect

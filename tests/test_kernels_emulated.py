@@ -96,3 +96,18 @@ def test_lds_kernel_pk_rounds(emu, oracle, traj_golden):
     assert not st.any()
     for r, got in zip(rows, ss):
         assert got == r["mfe_ss"]
+
+
+# ---- outside recursion / ensemble defect (fold_outside.hpp after the general pf_kernel)
+
+@pytest.mark.parametrize("L,nt", [(5, 64), (12, 64), (36, 128), (70, 128), (97, 256)])
+def test_outside_kernel_bpp_and_defect(emu, oracle, L, nt):
+    rng = np.random.default_rng(500 + L)
+    seqs = [_rand(rng, L), _rand(rng, L), _rand(rng, L, "GC")]
+    target = oracle.mfe(seqs[0])[0]
+    ed, st, B = emu.edef(seqs, target, nt=nt, bpp=True)
+    assert not st.any()
+    for k, s in enumerate(seqs):
+        oe, ob = oracle.ensemble_defect(s, target, want_bpp=True)
+        assert abs(ed[k] - oe) < 1e-12, s
+        assert np.abs(B[k] - ob).max() < 1e-12, s
