@@ -459,17 +459,22 @@ extern "C" int drna_simscore_batch(int R, int L, const char* ref, const char* qu
   return DRNA_OK;
 }
 
-extern "C" int drna_propose_batch(int R, int L, const char* target, const unsigned char* allowed_mask, const char* seqs,
-                                  const char* mfe_ss, const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min,
-                                  int targeted, uint64_t* rng_state, char* out_seqs) {
+// one proposal per replica; pt_design = partner of every design pair (target + ordinary alternative pairs), snakes optional
+static int propose_impl(int R, int L, const char* target, const int32_t* partner, const unsigned char* allowed_mask,
+                        const int32_t* snake_of, const int32_t* snake_off, const int32_t* snake_nodes,
+                        const int32_t* snake_nstates, const char* snake_states, const char* seqs, const char* mfe_ss,
+                        const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
+                        uint64_t* rng_state, char* out_seqs) {
   using namespace drna_host;
-  if (R < 0 || L < 1 || L > 2048 || !target || !allowed_mask || (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
-    return DRNA_ERR_ARG;
   static const char LET[4] = {'A', 'C', 'G', 'U'};
   static const unsigned CANPAIR[4] = {8u, 4u, 2u | 8u, 1u | 4u};   // A-U, C-G, G-C/U, U-A/G
-  std::vector<int> pt(L), pq(L), mutable_pos, pool;
+  std::vector<int> pt(L), pd(L), pq(L), mutable_pos, pool;
   std::vector<char> mark(L);
   if (!pair_table(target, L, pt.data())) return DRNA_ERR_STRUCTURE;
+  for (int i = 0; i < L; i++) {
+    pd[i] = partner ? partner[i] : pt[i];
+    if (pd[i] >= L || (pd[i] >= 0 && (partner ? partner[pd[i]] : pt[pd[i]]) != i)) return DRNA_ERR_ARG;
+  }
   for (int i = 0; i < L; i++)
     if (__builtin_popcount(allowed_mask[i] & 15u) != 1) mutable_pos.push_back(i);
   if (mutable_pos.empty()) return DRNA_ERR_ARG;
@@ -502,8 +507,24 @@ extern "C" int drna_propose_batch(int R, int L, const char* target, const unsign
     if (pos < 0) pos = mutable_pos[rnd_below(st, (int)mutable_pos.size())];
     const unsigned am = allowed_mask[pos] & 15u;
     const int cur = letter_index(s[pos]);
-    const int j = pt[pos];
-    if (j < 0) {
+    const int j = pd[pos];
+    if (snake_of && snake_of[pos] >= 0) {
+      // alternative structures: the whole connected component moves to another of its Watson-Crick colourings
+      // (reference utils/sequence_utils.py:1081-1095)
+      const int k = snake_of[pos], n0 = snake_off[k], len = snake_off[k + 1] - n0, ns = snake_nstates[k];
+      const char* states = snake_states + (size_t)4 * n0;
+      int x = 0;
+      while (x < len && snake_nodes[n0 + x] != pos) x++;
+      if (x == len) return DRNA_ERR_ARG;
+      int curst = -1;
+      for (int q = 0; q < ns; q++) if (states[(size_t)q * len + x] == s[pos]) { curst = q; break; }
+      const int nopt = ns - (curst >= 0 ? 1 : 0);
+      if (nopt > 0) {
+        int pick = rnd_below(st, nopt);
+        if (curst >= 0 && pick >= curst) pick++;
+        for (int y = 0; y < len; y++) o[snake_nodes[n0 + y]] = states[(size_t)pick * len + y];
+      }
+    } else if (j < 0) {
       unsigned opts = __builtin_popcount(am) > 1 ? (am & ~(1u << cur)) : 0u;
       if (opts) {
         int k = rnd_below(st, __builtin_popcount(opts));
@@ -523,6 +544,38 @@ extern "C" int drna_propose_batch(int R, int L, const char* target, const unsign
     }
   }
   return DRNA_OK;
+}
+
+extern "C" int drna_propose_batch(int R, int L, const char* target, const unsigned char* allowed_mask, const char* seqs,
+                                  const char* mfe_ss, const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min,
+                                  int targeted, uint64_t* rng_state, char* out_seqs) {
+  if (R < 0 || L < 1 || L > 2048 || !target || !allowed_mask || (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
+    return DRNA_ERR_ARG;
+  return propose_impl(R, L, target, nullptr, allowed_mask, nullptr, nullptr, nullptr, nullptr, nullptr, seqs, mfe_ss,
+                      shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state, out_seqs);
+}
+
+extern "C" int drna_propose_batch_alt(int R, int L, const char* target, const int32_t* partner,
+                                      const unsigned char* allowed_mask, const int32_t* snake_of, int n_snakes,
+                                      const int32_t* snake_off, const int32_t* snake_nodes, const int32_t* snake_nstates,
+                                      const char* snake_states, const char* seqs, const char* mfe_ss,
+                                      const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
+                                      uint64_t* rng_state, char* out_seqs) {
+  if (R < 0 || L < 1 || L > 2048 || !target || !partner || !allowed_mask || n_snakes < 0 ||
+      (n_snakes > 0 && (!snake_of || !snake_off || !snake_nodes || !snake_nstates || !snake_states)) ||
+      (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
+    return DRNA_ERR_ARG;
+  for (int k = 0; k < n_snakes; k++) {
+    if (snake_off[k] < 0 || snake_off[k + 1] <= snake_off[k] || snake_nstates[k] < 1 || snake_nstates[k] > 4) return DRNA_ERR_ARG;
+    for (int x = snake_off[k]; x < snake_off[k + 1]; x++)
+      if (snake_nodes[x] < 0 || snake_nodes[x] >= L || snake_of[snake_nodes[x]] != k) return DRNA_ERR_ARG;
+  }
+  if (n_snakes > 0)
+    for (int i = 0; i < L; i++)
+      if (snake_of[i] >= n_snakes) return DRNA_ERR_ARG;
+  return propose_impl(R, L, target, partner, allowed_mask, n_snakes ? snake_of : nullptr, snake_off, snake_nodes,
+                      snake_nstates, snake_states, seqs, mfe_ss, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state,
+                      out_seqs);
 }
 
 extern "C" int drna_metropolis_batch(int R, const double* score_o, const double* score_m, const double* temps, double Lconst,

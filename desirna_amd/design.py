@@ -18,7 +18,10 @@ What is different by design: the R chains advance in LOCK-STEP -- one proposal p
 are statistically equivalent, not draw-for-draw identical: the reference itself is not reproducible across
 processes (it iterates over ``set`` objects of strings, whose order depends on PYTHONHASHSEED).
 
-Not supported here (raises): alternative-structure "snake" moves, two-strand inputs, ``-nd``, ``-acgu``.
+Alternative structures: "snake" moves (connected components of the pair graph of target + alternative structures
+switch between their Watson-Crick colourings) as in the reference (:143-388, :1081-1095).
+
+Not supported here (raises): two-strand inputs, ``-nd``, ``-acgu``.
 """
 import argparse
 import random
@@ -61,7 +64,7 @@ def read_input(path):
 class DesignProblem:
     """Target structure + restraints -> per-position letter sets and pairing partners (reference get_nt_list)."""
 
-    def __init__(self, sec_struct, seq_restr=None):
+    def __init__(self, sec_struct, seq_restr=None, alt_sec_structs=None):
         if "&" in sec_struct:
             raise NotImplementedError("two-strand design inputs are not part of the GPU path yet")
         self.sec_struct = sec_struct
@@ -69,8 +72,13 @@ class DesignProblem:
         self.seq_restr = seq_restr or "N" * n
         if len(self.seq_restr) != n:
             raise ValueError("Secondary structure and sequence restraints are of different length. Check input file.")
-        self.partner = pair_table(sec_struct)                 # all bracket families count as design pairs
-        self.pairs = {(i, int(p)) for i, p in enumerate(self.partner) if p > i}
+        self.partner = pair_table(sec_struct).copy()          # all bracket families count as design pairs
+        self.target_pairs = {(i, int(p)) for i, p in enumerate(self.partner) if p > i}
+        self.pairs = set(self.target_pairs)
+        self.snakes = []                                      # [(positions, [state strings])]
+        self.snake_of = [-1] * n
+        if alt_sec_structs:
+            self._build_snakes(alt_sec_structs)
         letters = []
         for ch in self.seq_restr:
             if ch not in IUPAC:
@@ -87,6 +95,66 @@ class DesignProblem:
         self.letters, self.allowed = letters, allowed
         self.mutable = [i for i in range(n) if len(allowed[i]) != 1]
         self.n = n
+        for k, (nodes, states) in enumerate(self.snakes):
+            ok = [st for st in states if all(st[x] in letters[v] for x, v in enumerate(nodes))]
+            if not ok:
+                raise ValueError("The structural restraints are contradictive to sequence restraints. Check your input.")
+            self.snakes[k] = (nodes, ok)
+
+    def _build_snakes(self, alt_sec_structs):
+        """Alternative structures (reference get_pairs_for_graphs / generate_graphs / update_graphs,
+        utils/sequence_utils.py:143-388): the pairs of all structures form a graph; a pair with an end that
+        also sits in another pair belongs to a "snake" (a connected component that must be two-coloured with one
+        Watson-Crick letter pair: A/U, U/A, C/G or G/C); the remaining alternative pairs become ordinary design
+        pairs.  State order follows the reference: colour 0 goes to the component's first vertex in the
+        reference's traversal; both colourings are in the list, so only the order depends on it."""
+        n = len(self.sec_struct)
+        alt = set()
+        for a in alt_sec_structs:
+            if len(a) != n:
+                raise ValueError("alternative structure and target are of different length")
+            pt = pair_table(a)
+            alt |= {(i, int(p)) for i, p in enumerate(pt) if p > i}
+        merged = self.target_pairs | alt
+        count = [0] * n
+        for a, b in merged:
+            count[a] += 1
+            count[b] += 1
+        graph_pairs = sorted(p for p in merged if count[p[0]] > 1 or count[p[1]] > 1)
+        excluded = sorted(p for p in merged if not (count[p[0]] > 1 or count[p[1]] > 1))
+        for a, b in excluded:                                 # ordinary pairs (the target's own ones are already there)
+            self.pairs.add((a, b))
+            self.partner[a], self.partner[b] = b, a
+        adj = {}
+        for a, b in graph_pairs:
+            adj.setdefault(a, []).append(b)
+            adj.setdefault(b, []).append(a)
+        seen = set()
+        comps = []
+        for v in sorted(adj):
+            if v in seen:
+                continue
+            colour = {v: 0}
+            queue = [v]
+            while queue:
+                x = queue.pop(0)
+                for y in adj[x]:
+                    if y not in colour:
+                        colour[y] = 1 - colour[x]
+                        queue.append(y)
+                    elif colour[y] == colour[x]:
+                        raise ValueError("The structural restraints in the alternative structures cannot be solved. "
+                                         "Check your input.")
+            seen |= set(colour)
+            nodes = sorted(colour)
+            cols = [colour[x] for x in nodes]
+            states = ["".join(m[c] for c in cols) for m in ("AU", "UA", "CG", "GC")]
+            comps.append((nodes, states))
+        comps.sort(key=lambda c: c[0][0])
+        self.snakes = comps
+        for k, (nodes, _) in enumerate(comps):
+            for v in nodes:
+                self.snake_of[v] = k
 
     def initial_sequence(self, rng):
         """reference initial_sequence_generator with -acgu off: unpaired -> A, first base of an unpaired stretch (length
@@ -124,6 +192,9 @@ class DesignProblem:
         for i in range(n):
             if s[i] not in "ACGU":
                 s[i] = rng.choice(IUPAC[s[i]])
+        for nodes, states in self.snakes:                     # reference :750-760: every snake starts in its first state
+            for x, v in enumerate(nodes):
+                s[v] = states[0][x]
         return "".join(s)
 
     # ---- move set
@@ -133,7 +204,7 @@ class DesignProblem:
         q = pair_table(mfe_ss)
         query = {(i, int(p)) for i, p in enumerate(q) if p > i}
         mutable = set(self.mutable)
-        false_cases = {x for pr in (self.pairs - query) | (query - self.pairs) for x in pr if x in mutable}
+        false_cases = {x for pr in (self.target_pairs - query) | (query - self.target_pairs) for x in pr if x in mutable}
         if not false_cases:
             return rng.choice(self.mutable)
         prob = round(float(np.linspace(tm_max, tm_min, num=n_shelves)[shelf_index]), 2)
@@ -144,7 +215,16 @@ class DesignProblem:
     def mutate(self, seq, pos, rng):
         s = list(seq)
         j = int(self.partner[pos])
-        if j < 0:
+        if self.snake_of[pos] >= 0:                           # reference :1081-1095: move the whole snake to another state
+            nodes, states = self.snakes[self.snake_of[pos]]
+            x = nodes.index(pos)
+            cur = next((st for st in states if st[x] == s[pos]), None)
+            new_states = [st for st in states if st != cur]
+            if new_states:
+                st = rng.choice(new_states)
+                for y, v in enumerate(nodes):
+                    s[v] = st[y]
+        elif j < 0:
             opts = [x for x in self.allowed[pos] if x != s[pos]] if len(self.allowed[pos]) > 1 else []
             if opts:
                 s[pos] = rng.choice(opts)
@@ -164,9 +244,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
 
     ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
     own replicas and all-gathers the scores before each exchange attempt."""
-    if input_file.alt_sec_struct is not None:
-        raise NotImplementedError("alternative-structure 'snake' moves are not part of the batched driver yet")
-    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr)
+    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
     pks = "on" if set(input_file.sec_struct) - set(".()&") else "off"
     opts = SimpleNamespace(oligo_state="none", pks=pks, subopt="off", motifs=None, param="1999",
                            scoring_f=es.parse_scoring_functions(scoring_f))
@@ -239,9 +317,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.
     Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
     from . import engine as _engine
-    if input_file.alt_sec_struct is not None:
-        raise NotImplementedError("alternative-structure 'snake' moves are not part of the batched driver yet")
-    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr)
+    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
+    n_alt = len(input_file.alt_sec_structs) if input_file.alt_sec_structs else 0
     sf = es.parse_scoring_functions(scoring_f)
     for name, _ in sf:
         if name not in es.AVAILABLE_SCORING_FUNCTIONS:
@@ -249,7 +326,7 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     R, L = replicas, prob.n
     eng = engine or _engine.Engine(max_R=R, max_L=L, device=device)
     hk = _engine.HostKernels()
-    eng.set_targets([input_file.sec_struct])
+    eng.set_targets([input_file.sec_struct] + list(input_file.alt_sec_structs or []))
     flags = _engine.NEED_PF | _engine.NEED_MFE | _engine.NEED_EVAL
     if set(input_file.sec_struct) - set(".()&"):
         flags |= _engine.NEED_PK
@@ -279,6 +356,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
                 total += (1 - rec) * 10 * w
             elif name == "Edef":
                 total += eng.ensemble_defect_arrays(seqs_u8) * w
+        if n_alt:                                                 # reference energy_scores.py:98-102
+            total += Ed[:, 1:].sum(axis=1) / 100.0 / n_alt - Epf
         return total, 1 - mcc, ss, Epf, ed
 
     init = prob.initial_sequence(main_rng)
@@ -303,7 +382,10 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         rng_state = np.arange(R, dtype=np.uint64)                # re-seeded with the replica index every exchange step
         shelf_idx = np.searchsorted(shelves, temps).astype(np.int32)
         for _ in range(exchange):
-            prop = hk.propose(ref_ss, amask, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
+            if prob.snakes or n_alt:
+                prop = hk.propose_alt(prob, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
+            else:
+                prop = hk.propose(ref_ss, amask, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
             p_score, p_mcc, p_ss, p_epf, p_ed = score(prop)
             acc, better = hk.metropolis(cur_score, p_score, temps, rng_state)
             cur[acc] = prop[acc]; cur_ss[acc] = p_ss[acc]

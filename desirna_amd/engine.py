@@ -24,7 +24,7 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing")
+           "drna_last_edef_timing", "drna_propose_batch_alt")
 
 
 class EngineError(RuntimeError):
@@ -68,6 +68,9 @@ def load_library(path=None):
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
     L.drna_propose_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp, ci, C.c_double, C.c_double, ci, vp, vp]
+    L.drna_propose_batch_alt.restype = ci
+    L.drna_propose_batch_alt.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, C.c_double,
+                                         C.c_double, ci, vp, vp]
     L.drna_metropolis_batch.restype = ci
     L.drna_metropolis_batch.argtypes = [ci, vp, vp, vp, C.c_double, vp, vp, vp]
     return L
@@ -222,6 +225,38 @@ class HostKernels:
             raise EngineError(rc, "drna_propose_batch")
         return out
 
+    def propose_alt(self, prob, seqs_u8, ss_u8, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state):
+        """Proposals for a ``design.DesignProblem`` that may hold alternative-structure snakes."""
+        s = np.ascontiguousarray(seqs_u8, dtype=np.uint8)
+        R, L = s.shape
+        out = np.empty_like(s)
+        ss = np.ascontiguousarray(ss_u8, dtype=np.uint8)
+        pk = getattr(prob, "_native_pack", None)
+        if pk is None:
+            am = np.array([sum(1 << "ACGU".index(c) for c in a) for a in prob.allowed], dtype=np.uint8)
+            partner = np.ascontiguousarray(prob.partner, dtype=np.int32)
+            snake_of = np.ascontiguousarray(prob.snake_of, dtype=np.int32)
+            off, nodes, nst, chars = [0], [], [], b""
+            for nd, states in prob.snakes:
+                nodes += list(nd)
+                off.append(len(nodes))
+                nst.append(len(states))
+                chars += "".join(states).encode() + b"." * (len(nd) * (4 - len(states)))
+            pk = (am, partner, snake_of, np.array(off, dtype=np.int32), np.array(nodes or [0], dtype=np.int32),
+                  np.array(nst or [0], dtype=np.int32), np.frombuffer(chars or b".", dtype=np.uint8).copy())
+            prob._native_pack = pk
+        am, partner, snake_of, off, nodes, nst, chars = pk
+        sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
+        assert rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+        rc = self._L.drna_propose_batch_alt(R, L, prob.sec_struct.encode("ascii"), partner.ctypes.data, am.ctypes.data,
+                                            snake_of.ctypes.data, len(prob.snakes), off.ctypes.data, nodes.ctypes.data,
+                                            nst.ctypes.data, chars.ctypes.data, s.ctypes.data, ss.ctypes.data, sh.ctypes.data,
+                                            int(n_shelves), float(tm_max), float(tm_min), int(bool(targeted)),
+                                            rng_state.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_propose_batch_alt")
+        return out
+
     def metropolis(self, score_o, score_m, temps, rng_state, L_const=504.12):
         so = np.ascontiguousarray(score_o, dtype=np.float64)
         sm = np.ascontiguousarray(score_m, dtype=np.float64)
@@ -233,5 +268,5 @@ class HostKernels:
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
             raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing")
+           "drna_last_edef_timing", "drna_propose_batch_alt")
         return acc.astype(bool), bet.astype(bool)

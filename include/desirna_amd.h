@@ -145,6 +145,23 @@ int drna_propose_batch(int R, int L, const char *target, const unsigned char *al
                        int targeted, uint64_t *rng_state, char *out_seqs);
 
 /*
+ * drna_propose_batch_alt: the same move set for targets WITH alternative structures (>alt_sec_struct): positions that sit
+ * in a "snake" (a connected component of the pair graph of target + alternative structures, utils/sequence_utils.py:143-388)
+ * move the whole component to another of its Watson-Crick colourings (:1081-1095); alternative pairs outside snakes are
+ * ordinary design pairs.
+ *   partner        L int32: partner of every design pair (target pairs + ordinary alternative pairs), -1 = none
+ *   snake_of       L int32: snake index of a position or -1 (may be NULL when n_snakes == 0)
+ *   snake_off      n_snakes+1 int32: snake k owns snake_nodes[snake_off[k] .. snake_off[k+1])  (ascending positions)
+ *   snake_nstates  n_snakes int32 (1..4); snake_states: for snake k, 4 slots of len_k letters at 4*snake_off[k]
+ * False negatives / positives of the targeted-mutation rule are taken against `target` only (input_file.target_pairs_tupl).
+ */
+int drna_propose_batch_alt(int R, int L, const char *target, const int32_t *partner, const unsigned char *allowed_mask,
+                           const int32_t *snake_of, int n_snakes, const int32_t *snake_off, const int32_t *snake_nodes,
+                           const int32_t *snake_nstates, const char *snake_states, const char *seqs, const char *mfe_ss,
+                           const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
+                           uint64_t *rng_state, char *out_seqs);
+
+/*
  * drna_metropolis_batch: mc_delta of utils/replica_exchange_monte_carlo.py:26-57 for R replicas: accept iff
  * score_m <= score_o, else with probability exp(-Lconst / T * (score_m - score_o)) (one draw, only then).
  */

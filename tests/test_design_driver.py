@@ -170,3 +170,68 @@ def test_fast_driver_solves_L200_on_gpu(eterna_targets):
                           alt_sec_structs=None)
     res = design.run_design_fast(inp, replicas=64, exchange=100, steps=6, seed=1, stop_when_solved=True)
     assert res["solved"] and res["stats"]["scored"] >= 64
+
+
+# ---- alternative structures: snakes (reference utils/sequence_utils.py:143-388, :1081-1095)
+
+ALT_TARGET = "((((((.((((((((....))))).)).).))))))"
+ALT_STRUCTS = ["(((((((((((((....)))..)).)).).))))).",
+               "(((((((((((((....)))))...)).).))))).",
+               ]
+
+
+def _snake_invariants(p, s):
+    for nodes, states in p.snakes:
+        assert "".join(s[v] for v in nodes) in states
+    for i, j in p.pairs:
+        if p.snake_of[i] < 0:
+            assert s[j] in design.CAN_PAIR[s[i]]
+    # every pair of the target AND of every alternative structure can form (Watson-Crick inside snakes)
+    for st in [ALT_TARGET] + ALT_STRUCTS:
+        pt = design.pair_table(st)
+        for i, j in enumerate(pt):
+            if j > i:
+                assert s[int(j)] in design.CAN_PAIR[s[i]], (st, i, j)
+
+
+def test_native_snake_proposals(hk):
+    import numpy as np
+    p = design.DesignProblem(ALT_TARGET, "N" * len(ALT_TARGET), ALT_STRUCTS)
+    assert len(p.snakes) == 2
+    R = 16
+    seq = p.initial_sequence(random.Random(3))
+    _snake_invariants(p, seq)
+    cur = np.tile(np.frombuffer(seq.encode(), dtype=np.uint8), (R, 1)).copy()
+    ss = np.tile(np.frombuffer(("." * p.n).encode(), dtype=np.uint8), (R, 1)).copy()
+    rng = np.arange(R, dtype=np.uint64)
+    moved_snake = 0
+    for it in range(40):
+        out = hk.propose_alt(p, cur, ss, np.zeros(R, dtype=np.int32), R, 0.7, 0.0, True, rng)
+        for r in range(R):
+            s = out[r].tobytes().decode()
+            _snake_invariants(p, s)
+            moved_snake += sum(a != b for a, b in zip(s, cur[r].tobytes().decode())) > 2
+        cur = out
+    assert moved_snake > 0
+    # Python mirror keeps the same invariants
+    rr = random.Random(5)
+    s = seq
+    for _ in range(200):
+        pos = p.mutation_position("." * p.n, 0, 10, 0.7, 0.0, True, rr)
+        s = p.mutate(s, pos, rr)
+        _snake_invariants(p, s)
+
+
+@pytest.mark.gpu
+def test_alt_structure_design_on_gpu():
+    """Alternative-structures example input through both drivers: score = (Ed - Epf) + (mean Ed_alt - Epf)."""
+    inp = SimpleNamespace(name="alt", sec_struct=ALT_TARGET, seq_restr="N" * len(ALT_TARGET), seed_seq=None,
+                          alt_sec_struct=ALT_STRUCTS[0], alt_sec_structs=ALT_STRUCTS)
+    res = design.run_design_fast(inp, replicas=16, exchange=50, steps=4, seed=2)
+    b = res["best"]
+    p = design.DesignProblem(ALT_TARGET, inp.seq_restr, ALT_STRUCTS)
+    _snake_invariants(p, b.sequence)
+    res2 = design.run_design(inp, replicas=8, exchange=10, steps=2, seed=2)
+    _snake_invariants(p, res2["best"].sequence)
+    sc = res2["best"]
+    assert abs(sc.scoring_function - (sc.edesired_minus_Epf + sc.edesired2_minus_Epf)) < 1e-9

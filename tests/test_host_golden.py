@@ -1,0 +1,122 @@
+"""Host rows of the hot path against vectors recorded from the reference's own Python (tools/make_host_golden.py,
+run once in the build container with a no-arithmetic stand-in for the absent ViennaRNA module): temperature ladder,
+Metropolis, replica exchange, input parsing, design problem (pairs, allowed letters, snakes), initial sequences and
+proposals -- including the number of random draws each consumes (``next_random``)."""
+import json
+import os
+import random
+from types import SimpleNamespace
+
+import pytest
+
+from desirna_amd import design, replica_exchange as rx
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_golden.json")))
+CAN_PAIR = {'A': 'U', 'U': 'GA', 'G': 'UC', 'C': 'G'}
+
+
+def test_rep_temps():
+    for c in GOLD["rep_temps"]:
+        assert rx.get_rep_temps(c["R"], c["T_min"], c["T_max"]) == c["temps"]
+
+
+def test_mc_delta_draw_for_draw():
+    for c in GOLD["mc_delta"]:
+        rng = random.Random(c["seed"])
+        acc, better = rx.mc_delta(c["score_o"], c["score_m"], c["T"], rng)
+        assert (bool(acc), bool(better)) == (c["accept"], c["better"])
+        assert rng.random() == c["next_random"]
+
+
+def test_replica_exchange_draw_for_draw():
+    for c in GOLD["exchange"]:
+        rng = random.Random(c["seed"])
+        new_temps, acc, better, rej = rx.replica_exchange(c["temps"], c["scores"], c["global_step"], rng)
+        assert new_temps == c["new_temps"]
+        assert (acc, better, rej) == (c["acc"], c["acc_better"], c["rej"])
+        assert rng.random() == c["next_random"]
+
+
+def _write_input(tmp_path, name, d):
+    txt = ">name\n%s\n>seq_restr\n%s\n>sec_struct\n%s\n" % (d["name"], d["seq_restr"], d["sec_struct"])
+    if d["seed_seq"]:
+        txt += ">seed_seq\n%s\n" % d["seed_seq"]
+    if d["alt_sec_structs"]:
+        txt += ">alt_sec_struct\n%s\n" % "\n".join(d["alt_sec_structs"])
+    p = tmp_path / (name + ".txt")
+    p.write_text(txt)
+    return str(p)
+
+
+def test_read_input_roundtrip(tmp_path):
+    for name, d in GOLD["inputs"].items():
+        inp = design.read_input(_write_input(tmp_path, name, d))
+        assert (inp.name, inp.sec_struct, inp.seq_restr, inp.seed_seq, inp.alt_sec_structs) == \
+               (d["name"], d["sec_struct"], d["seq_restr"], d["seed_seq"], d["alt_sec_structs"])
+
+
+def _problem(name):
+    d = GOLD["inputs"][name]
+    return design.DesignProblem(d["sec_struct"], d["seq_restr"], d["alt_sec_structs"])
+
+
+def test_design_problem_pairs_letters_snakes():
+    for name, g in GOLD["problems"].items():
+        prob = _problem(name)
+        assert sorted([list(p) for p in prob.pairs]) == g["pairs"]
+        assert sorted([list(p) for p in prob.target_pairs]) == g["target_pairs"]
+        assert ["".join(sorted(a)) for a in prob.allowed] == g["letters_allowed"]
+        assert [int(p) for p in prob.partner] == g["pairs_with"]
+        assert [s >= 0 for s in prob.snake_of] == g["snake"]
+        if g["graphs"] is None:
+            assert prob.snakes == []
+        else:
+            assert [n for n, _ in prob.snakes] == [x["numbers"] for x in g["graphs"]]
+            for (_, states), x in zip(prob.snakes, g["graphs"]):
+                assert sorted(states) == sorted(x["states"])     # same set; order depends on the reference's set iteration
+
+
+def test_initial_sequence():
+    """Same construction rule; letters drawn at random (G/C vs C/G of a pair, the first snake state) may differ, so the
+    check is structural: unpaired -> A / loop-start G, every design pair Watson-Crick G/C where allowed, snakes in one state."""
+    for c in GOLD["initial"]:
+        prob = _problem(c["input"])
+        ref = c["sequence"]
+        mine = prob.initial_sequence(random.Random(c["seed"]))
+        for i in range(prob.n):
+            if prob.partner[i] < 0 and prob.snake_of[i] < 0:
+                assert mine[i] == ref[i], (c["input"], i)
+        for i, j in prob.pairs:
+            if prob.snake_of[i] < 0 and prob.snake_of[j] < 0:
+                assert {mine[i], mine[j]} == {ref[i], ref[j]}
+        for nodes, states in prob.snakes:
+            assert "".join(mine[v] for v in nodes) in states and "".join(ref[v] for v in nodes) in states
+
+
+def test_proposals_same_position_and_draws():
+    """mutate_sequence with random.seed(k): the mirror must pick the same position(s), consume the same number of draws
+    and produce the same letters, except where the reference's own choice depends on str-set iteration order (second
+    letter of a pair move with two compatible options; snake state order): there the result must be a legal alternative."""
+    n_exact = 0
+    for c in GOLD["proposals"]:
+        prob = _problem(c["input"])
+        rng = random.Random(c["seed"])
+        pos = prob.mutation_position(c["mfe_ss"], c["shelf"], c["n_shelves"], 0.7, 0.0, True, rng)
+        mine = prob.mutate(c["sequence"], pos, rng)
+        ref = c["proposed"]
+        assert rng.random() == c["next_random"], c
+        dm = [i for i in range(prob.n) if mine[i] != c["sequence"][i]]
+        dr = [i for i in range(prob.n) if ref[i] != c["sequence"][i]]
+        if mine == ref:
+            n_exact += 1
+            continue
+        if prob.snake_of[pos] >= 0:
+            nodes, states = prob.snakes[prob.snake_of[pos]]
+            assert set(dr) <= set(nodes) and "".join(ref[v] for v in nodes) in states
+            assert "".join(mine[v] for v in nodes) in states
+        else:
+            j = int(prob.partner[pos])
+            assert j >= 0 and set(dm) <= {pos, j} and set(dr) <= {pos, j}
+            assert mine[pos] == ref[pos]                          # first letter: sorted list, deterministic
+            assert mine[j] in CAN_PAIR[mine[pos]] and ref[j] in CAN_PAIR[ref[pos]]
+    assert n_exact > len(GOLD["proposals"]) // 2
