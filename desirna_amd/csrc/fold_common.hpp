@@ -71,6 +71,21 @@ __device__ __forceinline__ int queue_pop(int* head, int lane) {
   return __builtin_amdgcn_readfirstlane(it);
 }
 
+// ---- buffer loads: 32-bit per-lane byte offset + wave-uniform (SGPR) byte offset, so an unrolled strided sweep costs
+// one VALU add per running offset instead of a 64-bit address computation per load
+template <typename RS>
+__device__ __forceinline__ double buf_load_f64(RS rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+
+struct f64x2 { double x, y; };
+template <typename RS>
+__device__ __forceinline__ f64x2 buf_load_f64x2(RS rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return f64x2{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
+}
+
 // ---- DPP wave reductions (no LDS traffic, fixed order => bit-reproducible)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {

@@ -62,6 +62,9 @@ struct FmlLds {
 
 // Diagnostic build only (-DDRNA_STAMPS): per-wave cycle totals of each phase of block 0, written to
 // an unused part of its workspace (never read by the kernel).
+#ifndef DRNA_SKIP
+#define DRNA_SKIP 0          // diagnostic builds only: see fold_pf_lds.hpp
+#endif
 #ifdef DRNA_STAMPS
 #define STAMP(k) do { long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
 #else
@@ -306,7 +309,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         const int lo = sh + off0, hi = ncell + sh + off0 - 1;
         const int tb_lo = lo >> 6, tb_hi = hi >> 6;
         // ---- T: tower step
-        if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
+        if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
           const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG, lane)
@@ -320,31 +323,47 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
         // pairable cells for the 112 bulge / 1xn shapes (E), then three groups of fixed small shapes per 64
         // pairable cells (X).  Minima are order-free, so who takes what does not matter.
-        const int nK = (ncell + 15) >> 4, nE = (pcnt + 1) >> 1, nX = 3 * ((pcnt + WAVE - 1) / WAVE);
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+                  nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
         const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
         const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
         const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
           if (it < nK) {
-            // ---- K: multiloop splits of 16 cells x 4 split-point groups; lane = cell + 16 g
+            // ---- K: multiloop splits of 32 cells x 4 interleaved split-point groups.  A lane owns two adjacent cells
+            // (one ds_read2 per operand pair) and walks the compact triangle with running offsets: row tt starts
+            // rowoff[tt+4] - rowoff[tt] = 4n - 4tt - 6 words after row tt-4... so offset += delta, delta -= 16 per step
+            // instead of a table lookup per operand.
             const int g = lane >> 4, cl = lane & 15;
-            int i = it * 16 + cl + 1;
-            const bool act = i <= ncell;
-            i = act ? i : ncell;
-            int acc0 = INF, acc1 = INF;
+            int i = (it << 5) + 2 * cl + 1;
+            const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+            i = act0 ? i : 1;
             int tt = TURN + 1 + g;
-            for (; tt + 12 <= d - TURN - 2; tt += 16) {
-              const int a0 = sm.fml[sm.rowoff[tt] + i - 1], c0 = sm.fml[sm.rowoff[d - tt - 1] + i + tt];
-              const int a1 = sm.fml[sm.rowoff[tt + 4] + i - 1], c1 = sm.fml[sm.rowoff[d - tt - 5] + i + tt + 4];
-              const int a2 = sm.fml[sm.rowoff[tt + 8] + i - 1], c2 = sm.fml[sm.rowoff[d - tt - 9] + i + tt + 8];
-              const int a3 = sm.fml[sm.rowoff[tt + 12] + i - 1], c3 = sm.fml[sm.rowoff[d - tt - 13] + i + tt + 12];
-              acc0 = min(acc0, min(a0 + c0, a2 + c2));
-              acc1 = min(acc1, min(a1 + c1, a3 + c3));
+            const int tmax = d - TURN - 2;
+            const int rr = tt <= tmax ? d - tt - 1 : TURN + 1;
+            int offA = fml_off(tt, n) + i - 1, dA = 4 * n - 4 * tt - 6;            // fML[i, i+tt]
+            int offC = fml_off(rr, n) + i + tt, dC = -4 * n + 4 * rr - 6;          // fML[i+tt+1, j]
+            int m0 = INF, m1 = INF, m2 = INF, m3 = INF;                            // cell i: m0, m2; cell i+1: m1, m3
+            for (; tt + 12 <= tmax; tt += 16) {
+              const int oA1 = offA + dA, oA2 = oA1 + dA - 16, oA3 = oA2 + dA - 32;
+              const int oC1 = offC + dC, oC2 = oC1 + dC - 16, oC3 = oC2 + dC - 32;
+              const int a00 = sm.fml[offA], a01 = sm.fml[offA + 1], c00 = sm.fml[offC], c01 = sm.fml[offC + 1];
+              const int a10 = sm.fml[oA1], a11 = sm.fml[oA1 + 1], c10 = sm.fml[oC1], c11 = sm.fml[oC1 + 1];
+              const int a20 = sm.fml[oA2], a21 = sm.fml[oA2 + 1], c20 = sm.fml[oC2], c21 = sm.fml[oC2 + 1];
+              const int a30 = sm.fml[oA3], a31 = sm.fml[oA3 + 1], c30 = sm.fml[oC3], c31 = sm.fml[oC3 + 1];
+              offA = oA3 + dA - 48; offC = oC3 + dC - 48; dA -= 64; dC -= 64;
+              m0 = min(m0, min(a00 + c00, a20 + c20)); m1 = min(m1, min(a01 + c01, a21 + c21));
+              m2 = min(m2, min(a10 + c10, a30 + c30)); m3 = min(m3, min(a11 + c11, a31 + c31));
             }
-            for (; tt <= d - TURN - 2; tt += 4) acc0 = min(acc0, sm.fml[sm.rowoff[tt] + i - 1] + sm.fml[sm.rowoff[d - tt - 1] + i + tt]);
-            acc0 = min(acc0, acc1);
-            if (act && acc0 < HALF) atomicMin(&sm.accK[par][i + slot0], acc0);
+            for (; tt <= tmax; tt += 4) {
+              m0 = min(m0, sm.fml[offA] + sm.fml[offC]);
+              m1 = min(m1, sm.fml[offA + 1] + sm.fml[offC + 1]);
+              offA += dA; offC += dC; dA -= 16; dC -= 16;
+            }
+            m0 = min(m0, m2); m1 = min(m1, m3);
+            if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
+            if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
           } else if (it < nK + nE) {
             // ---- E: two pairable cells, the 112 bulge / 1xn shapes over the lanes
             const int q = 2 * (it - nK);

@@ -129,6 +129,19 @@ __device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double
   return lo + hi;
 }
 
+// Diagnostic builds only (-DDRNA_SKIP=mask, tools/phase_cost.py): leave out a sweep phase to read its marginal cost
+// from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = finalize stores.
+#ifndef DRNA_SKIP
+#define DRNA_SKIP 0
+#endif
+#ifndef STAMP
+#ifdef DRNA_STAMPS
+#define STAMP(k) do { long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   __shared__ PfFastSmem<NT> sm;
@@ -226,6 +239,11 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   }
   __syncthreads();
 
+#ifdef DRNA_STAMPS
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_last = clock64();
+  long long* dbg = reinterpret_cast<long long*>(base + 5 * tab);     // the U table is unused by this kernel
+#endif
   if (aw < 0) {
     // ================= finalize waves: diagonal d = k-1 at step k
     for (int k = TURN + 1; k <= n; k++) {
@@ -298,7 +316,12 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       }
       // exterior column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier)
       if (wave == 0 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
+      STAMP(4);
       __syncthreads();
+      STAMP(3);
+#ifdef DRNA_STAMPS
+      if (blockIdx.x == 0 && tid == 0) dbg[256 + k] = st_acc[4];
+#endif
     }
   } else {
     // ================= sweep waves: diagonal d = k at step k
@@ -317,6 +340,10 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     const double x_b1 = keep_f64(T.bulge[1] * A.scale[3]), x_23 = keep_f64(T.interior[5] * T.eninio[1] * A.scale[7]);
     const double sc4 = keep_f64(A.scale[4]), sc5 = keep_f64(A.scale[5]), sc6 = keep_f64(A.scale[6]);
 
+    // QM and QM1 (adjacent tables) through one buffer descriptor
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
+    const int astep = 32 * ld, cstep = 32 * ld - 32;
+
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
         const int d = k;
@@ -325,39 +352,55 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         const int tb_lo = lo >> 6, tb_hi = hi >> 6;
         const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
         // ---- T: tower step
-        if (pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
+        if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
           const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g, lane) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g, lane);
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
         }
+        STAMP(0);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
         // ---- floating items of the diagonal, taken from a work queue (LDS counter): 16-cell multiloop
         // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
         // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
         // not depend on which wave takes it.
-        const int nK = (ncell + 15) >> 4, nE = (pcnt + 1) >> 1, nX = 3 * ((pcnt + WAVE - 1) / WAVE);
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+                  nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
         const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
         const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
         const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
           if (it < nK) {
+            // ---- K: multiloop sum D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j] for 32 cells x 4 interleaved split-point
+            // groups: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
+            // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
             const int g = lane >> 4, cl = lane & 15;
-            int i = it * 16 + cl + 1;
-            const bool act = i <= ncell;
-            i = act ? i : ncell;
-            double acc0 = 0.0, acc1 = 0.0;
+            int i = (it << 5) + 2 * cl + 1;
+            const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+            i = act0 ? i : 1;
+            double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
             int tt = TURN + 1 + g;
+            // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
+            // a step of 4 in tt moves them by +32 ld and -(32 ld - 32) bytes
+            int vA = (tt * ld + i) * 8;
+            int vC = (int)tab * 8 + ((d - tt - 13) * ld + i + tt + 13) * 8;          // operand of tt + 12
             for (; tt + 12 <= d - TURN - 2; tt += 16) {
-              const double a0 = QM[tt * ld + i], c0 = QM1[(d - tt - 1) * ld + i + tt + 1];
-              const double a1 = QM[(tt + 4) * ld + i], c1 = QM1[(d - tt - 5) * ld + i + tt + 5];
-              const double a2 = QM[(tt + 8) * ld + i], c2 = QM1[(d - tt - 9) * ld + i + tt + 9];
-              const double a3 = QM[(tt + 12) * ld + i], c3 = QM1[(d - tt - 13) * ld + i + tt + 13];
-              acc0 += a0 * c0; acc1 += a1 * c1; acc0 += a2 * c2; acc1 += a3 * c3;
+              const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
+              const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vC, 2 * cstep);
+              const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vC, cstep);
+              const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vC, 0);
+              vA += 4 * astep; vC -= 4 * cstep;
+              p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
+              p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
             }
-            for (; tt <= d - TURN - 2; tt += 4) acc0 += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
-            if (act) sm.partK[par][g][i + slot0] = acc0 + acc1;
+            for (; tt <= d - TURN - 2; tt += 4) {
+              const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
+              p0 += a0.x * c0.x; q0 += a0.y * c0.y;
+              vA += astep; vC -= cstep;
+            }
+            if (act0) sm.partK[par][g][i + slot0] = p0 + p1;
+            if (act1) sm.partK[par][g][i + 1 + slot0] = q0 + q1;
           } else if (it < nK + nE) {
             const int q = 2 * (it - nK);
             const bool two = q + 1 < pcnt;
@@ -419,12 +462,25 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
             }
             if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
           }
+#ifdef DRNA_STAMPS
+          STAMP(it < nK ? 5 : it < nK + nE ? 1 : 2);
+#endif
         }
+        STAMP(6);
       }
       __syncthreads();
+      STAMP(3);
+#ifdef DRNA_STAMPS
+      if (blockIdx.x == 0 && aw == 0 && lane == 0) dbg[512 + k] = st_last;
+      if (blockIdx.x == 0 && lane == 0) dbg[1024 + (wave - NB) * 256 + k] = st_acc[3];
+#endif
     }
   }
 
+#ifdef DRNA_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
+#endif
   // the remaining exterior columns, then Z
   if (wave == 0) {
     for (int j = max(TURN + 2, n - 2); j <= n; j++) pf_q5_column<NT>(sm, QEXT, ld, j, lane, sc1);

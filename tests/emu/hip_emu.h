@@ -87,6 +87,17 @@ static inline int __double2hiint(double v) { unsigned long long b; std::memcpy(&
 static inline double __hiloint2double(int hi, int lo) {
   unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double v; std::memcpy(&v, &b, 8); return v;
 }
+// buffer descriptor + raw buffer loads (byte offsets)
+struct emu_rsrc { const char* p; };
+struct emu_u32x2 { unsigned v[2]; unsigned operator[](int k) const { return v[k]; } };
+static inline emu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return emu_rsrc{(const char*)p}; }
+static inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(emu_rsrc r, int voff, int soff, int) {
+  emu_u32x2 o; std::memcpy(o.v, r.p + voff + soff, 8); return o;
+}
+struct emu_u32x4 { unsigned v[4]; unsigned operator[](int k) const { return v[k]; } };
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_rsrc r, int voff, int soff, int) {
+  emu_u32x4 o; std::memcpy(o.v, r.p + voff + soff, 16); return o;
+}
 static inline void __builtin_amdgcn_s_barrier() { pthread_barrier_wait(&emu_g->bar); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 static inline int atomicMin(int* p, int v) {

@@ -29,3 +29,24 @@ print("per-wave cycles (block 0), total over %d diagonals" % (L - 4))
 for w in range(16):
     print("wave %2d " % w + "  ".join("%s=%7d" % (names[k], st[w, k]) for k in range(6)), " sum=%d" % st[w, :6].sum())
 
+
+# ---- PF kernel: stamps live in the (unused) U table of block 0
+tab = ld * ld
+eng._L.drna_debug_read_pf_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+pbuf = np.zeros(1024 + 12 * 256, dtype=np.float64)
+rc = eng._L.drna_debug_read_pf_ws(eng._h, 5 * tab, pbuf.size, pbuf.ctypes.data)
+pst = pbuf.view(np.int64)
+names = ["T", "E", "X", "barrier", "finalize", "K", "queue-empty pop"]
+print("PF per-wave cycles (block 0)")
+for w in range(16):
+    print("wave %2d " % w + "  ".join("%s=%7d" % (names[k], pst[w * 8 + k]) for k in range(7)), " sum=%d" % pst[w * 8:w * 8 + 7].sum())
+t = pst[512:512 + L + 1]
+dt = np.diff(t[4:L + 1])
+print("PF per-diagonal cycles (sweep wave 0, barrier to barrier), d = 5 ..:")
+print(" ".join("%d" % x for x in dt))
+fin = np.diff(pst[256 + 4:256 + L + 1])
+print("PF finalize busy cycles per step (thread 0):")
+print(" ".join("%d" % x for x in fin))
+bw = np.array([np.diff(pst[1024 + a * 256 + 4:1024 + a * 256 + L + 1]) for a in range(12)])
+print("PF sweep waves: barrier wait per diagonal, min / max over the 12 waves")
+print(" ".join("%d/%d" % (bw[:, k].min(), bw[:, k].max()) for k in range(bw.shape[1])))
