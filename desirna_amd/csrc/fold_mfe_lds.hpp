@@ -22,6 +22,7 @@
 namespace drna {
 
 constexpr int MFE_FAST_NMAX = 200;
+constexpr int EC = 4;              // pairable cells per bulge / 1xn work item
 constexpr int GSLOTS = 10;         // register-resident running minima per lane and parity (28 residues over >= 3 waves)
 
 template <int NT>
@@ -44,7 +45,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
-  int split_off[2][NL][2];       // byte offsets of the two operand rows of split point tt
+  int tw_L[32];                  // generic interior size term by total loop size s (INF below 6)
   int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
 };
 
@@ -84,20 +85,14 @@ __device__ __forceinline__ void mfe_f5_column(MfeFastSmem<NT>& sm, const int32_t
   sm.f5[j] = prev < m ? prev : m;
 }
 
-// Per-diagonal tables for diagonal d (written by the finalize waves one step ahead, so the sweep waves
-// spend no scalar instructions on offsets): split point tt -> byte offsets of fML[i,i+tt] and
-// fML[i+tt+1,j] relative to column i; residue rho of an inner diagonal -> ring offsets and size terms
-// of the tower entry that lives there on diagonal d.
+// Per-diagonal table for diagonal d (written by a finalize wave one step ahead, so the sweep waves spend
+// no scalar instructions on offsets): residue rho of an inner diagonal -> ring offsets and size terms of
+// the tower entry that lives there on diagonal d.
 template <int NT>
-__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, const MfeTables& T, int d, int n, int tid,
-                                                   int ninio, int max_ninio) {
+__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio) {
   constexpr int RS = MfeFastSmem<NT>::RS;
   const int par = d & 1;
-  if (tid >= TURN + 1 && tid <= d - TURN - 2) {
-    sm.split_off[par][tid][0] = (sm.rowoff[tid] - 1) * 4;
-    sm.split_off[par][tid][1] = (sm.rowoff[d - tid - 1] + tid) * 4;
-  }
-  if (tid < GRES) {
+  if (tid >= 0 && tid < GRES) {
     // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
     //   G <- min(max(G, floor), min(ring[A + i], ring[B + i]) + asym);  candidate = G + size
     // dead / not yet possible entries: asym = INF (G unchanged or INF), size = INF (no candidate)
@@ -112,7 +107,7 @@ __device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, const Mf
         offB = base + (s - 1) * 4;
         as = min(max_ninio, (s - 4) * ninio);
         fl = s <= 5 ? INF_DEV : -INF_DEV;                                // first appearance: forget the previous tenant
-        L = s >= 6 ? T.interior[s] : INF_DEV;
+        L = sm.tw_L[s];
       }
     }
     int* e = sm.tower_tab[par][tid];
@@ -183,6 +178,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   const int NG = NA / NB;                  // sweep waves pinned to one tower block (>= 3 for n <= 256, NT = 1024)
   const int my_tb = aw >= 0 ? aw / NG : NB, my_g = aw >= 0 ? aw - my_tb * NG : 0;
   const bool pinned = aw >= 0 && my_tb < NB;
+  const int w_tab = NB > 1 ? 1 : 0, w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
 
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
@@ -190,6 +186,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   for (int k = tid; k <= n; k += NT) { sm.hpl[k] = A.hp_len[k]; sm.rowoff[k] = k >= TURN + 1 ? fml_off(k, n) : 0; }
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
+  for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
   for (int k = tid; k < 64; k += NT) sm.stackp[k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
   for (int k = tid; k < 1024; k += NT) sm.int11p[k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
   for (int k = tid; k < 128; k += NT) {
@@ -217,7 +214,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   if (aw < 0) {
     const int d = TURN + 1;
     if (d < n) {
-      mfe_prepare_tables<NT>(sm, T, d, n, tid, ninio, max_ninio);
+      mfe_prepare_tables<NT>(sm, d, tid, ninio, max_ninio);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
@@ -273,16 +270,22 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           sm.fml[sm.rowoff[dv] + i - 1] = min(f, dec);
         }
       }
-      // tables and pairable list of diagonal k+1 (the sweep waves are reading those of diagonal k)
+      // side jobs of the step, one finalize wave each (when there are that many): tower table and pairable list of
+      // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
+      // <= k-4, were stored in step <= k-3 and drained by the barrier that ended that step)
       if (k + 1 < n) {
-        mfe_prepare_tables<NT>(sm, T, k + 1, n, tid, ninio, max_ninio);
-        const int cnt = PL[(k + 1) * ld + ld - 1];
-        if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
-        if (tid == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
+        if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio);
+        if (wave == w_pl) {
+          const int32_t* row = PL + (k + 1) * ld;
+          const int cnt = row[ld - 1];
+          const int p0 = row[lane], p1 = row[lane + WAVE], p2 = row[lane + 2 * WAVE], p3 = row[min(lane + 3 * WAVE, ld - 1)];
+          int* dst = sm.plist[(k + 1) & 1];
+          dst[lane] = p0; dst[lane + WAVE] = p1; dst[lane + 2 * WAVE] = p2;
+          if (lane + 3 * WAVE < MfeFastSmem<NT>::NL) dst[lane + 3 * WAVE] = p3;
+          if (lane == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
+        }
       }
-      // exterior column j = k-3 by wave 0: its cells (diagonals <= k-4) were stored in step <= k-3 and
-      // drained by the barrier that ended that step
-      if (wave == 0 && k - 3 >= TURN + 2) mfe_f5_column<NT>(sm, EXT, ld, k - 3, lane);
+      if (wave == w_q5 && k - 3 >= TURN + 2) mfe_f5_column<NT>(sm, EXT, ld, k - 3, lane);
       STAMP(4);
       __syncthreads();                     // one barrier per diagonal (drains vmcnt: c / EXT stores of this step)
       STAMP(3);
@@ -323,7 +326,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
         // pairable cells for the 112 bulge / 1xn shapes (E), then three groups of fixed small shapes per 64
         // pairable cells (X).  Minima are order-free, so who takes what does not matter.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + EC - 1) / EC,
                   nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
         const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
         const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
@@ -365,24 +368,29 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
             if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
           } else if (it < nK + nE) {
-            // ---- E: two pairable cells, the 112 bulge / 1xn shapes over the lanes
-            const int q = 2 * (it - nK);
-            const bool two = q + 1 < pcnt;
-            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
-            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
-            const int w00 = sm.wring[b_off + i0], w01 = sm.wring[o_off + i0];
-            const int w10 = sm.wring[b_off + i1], w11 = sm.wring[o_off + i1];
-            const int n00 = sm.mm1np[w01 & 127], n10 = sm.mm1np[w11 & 127];
-            const int m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
-            const int e00 = (w00 >> 8) + b_L + ((ij0 >> 4) > 2 ? TermAU : 0), e01 = (w01 >> 8) + o_L + n00 + m0;
-            const int e10 = (w10 >> 8) + b_L + ((ij1 >> 4) > 2 ? TermAU : 0), e11 = (w11 >> 8) + o_L + n10 + m1;
-            int v0 = min(b_ok ? e00 : INF, o_ok ? e01 : INF);
-            int v1 = min(b_ok ? e10 : INF, o_ok ? e11 : INF);
-            v0 = wave_min_i32_lane63(v0);
-            v1 = wave_min_i32_lane63(v1);
+            // ---- E: EC pairable cells per item, the 112 bulge / 1xn shapes over the lanes.  The cells' chains (list entry
+            // -> ring words -> table gathers -> wave minimum) are independent, so they overlap: an item is bound by
+            // LDS round-trip latency, not by issue.
+            const int q = EC * (it - nK);
+            int pe[EC], v[EC];
+#pragma unroll
+            for (int c = 0; c < EC; c++) pe[c] = sm.plist[par][as_vector(q + c < pcnt ? q + c : q)];
+            int wb[EC], wo[EC];
+#pragma unroll
+            for (int c = 0; c < EC; c++) { wb[c] = sm.wring[b_off + (pe[c] & 255)]; wo[c] = sm.wring[o_off + (pe[c] & 255)]; }
+#pragma unroll
+            for (int c = 0; c < EC; c++) {
+              const int ij = pe[c] >> 8;
+              const int eb = (wb[c] >> 8) + b_L + ((ij >> 4) > 2 ? TermAU : 0);
+              const int eo = (wo[c] >> 8) + o_L + sm.mm1np[wo[c] & 127] + sm.mm1n[ij];
+              v[c] = min(b_ok ? eb : INF, o_ok ? eo : INF);
+            }
+#pragma unroll
+            for (int c = 0; c < EC; c++) v[c] = wave_min_i32_lane63(v[c]);
             if (lane == WAVE - 1) {
-              if (v0 < HALF) atomicMin(&sm.accI[par][i0 + slot0], v0);
-              if (two && v1 < HALF) atomicMin(&sm.accI[par][i1 + slot0], v1);
+#pragma unroll
+              for (int c = 0; c < EC; c++)
+                if (q + c < pcnt && v[c] < HALF) atomicMin(&sm.accI[par][(pe[c] & 255) + slot0], v[c]);
             }
           } else {
             // ---- X: one group of fixed small shapes for 64 pairable cells (lane = compacted cell)

@@ -44,6 +44,7 @@ struct PfFastSmem {
   double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
+  double tw_as[32], tw_W[32];     // by total size s of a generic loop: asymmetry-independent factors (see pf_prepare_tables)
   double tw_d[2][32][3];          // per residue: asymmetry factor, keep factor (0 forgets the previous tenant), size factor
   int tw_i[2][32][2];             // per residue: byte offsets A, B into qbi
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
@@ -65,9 +66,9 @@ __device__ __forceinline__ void pf_q5_column(PfFastSmem<NT>& sm, const double* _
 }
 
 template <int NT>
-__device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, const PfTables& T, const double* scale, int d, int tid) {
+__device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, int d, int tid) {
   constexpr int RS = PfFastSmem<NT>::RS;
-  if (tid < GRES) {
+  if (tid >= 0 && tid < GRES) {
     // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
     //   G <- G * keep + (ring[A + i] + ring[B + i]) * asym;   contribution = G * size
     // dead entries: asym = 0, keep = 1, size = 0; entries without an inner pair yet: keep = 0, asym = 0
@@ -83,9 +84,9 @@ __device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, const PfTa
         const int base = (dp & 31) * RS * 8;
         offA = base + 3 * 8;
         offB = s == 4 ? zero_row : base + (s - 1) * 8;       // s = 4 has the single shape (2,2)
-        eas = T.eninio[s - 4];
+        eas = sm.tw_as[s];                                   // eninio[s - 4]
         keep = s <= 5 ? 0.0 : 1.0;
-        W = s >= 6 ? T.interior[s] * scale[s + 2] : 0.0;
+        W = sm.tw_W[s];                                      // s >= 6 ? interior[s] scale[s+2] : 0
       }
     }
     sm.tw_i[par][tid][0] = offA; sm.tw_i[par][tid][1] = offB;
@@ -130,7 +131,8 @@ __device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double
 }
 
 // Diagnostic builds only (-DDRNA_SKIP=mask, tools/phase_cost.py): leave out a sweep phase to read its marginal cost
-// from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = finalize stores.
+// from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = cell finalize, 32 = table / pairable-list
+// preparation, 64 = exterior column.
 #ifndef DRNA_SKIP
 #define DRNA_SKIP 0
 #endif
@@ -177,6 +179,10 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
+  for (int k = tid; k < 32; k += NT) {
+    sm.tw_as[k] = k >= 4 && k <= 30 ? T.eninio[k - 4] : 0.0;
+    sm.tw_W[k] = k >= 6 && k <= 30 ? T.interior[k] * A.scale[k + 2] : 0.0;
+  }
   for (int k = tid; k < 4 * RS; k += NT) sm.dring[k] = 0.0;
   for (int k = tid; k < RS; k += NT) sm.qbi[32 * RS + k] = 0.0;
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
@@ -227,11 +233,12 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   const int aw = wave - NB;                // index among the sweep waves (< 0: finalize wave)
   const int my_tb = aw >= 0 ? aw / PNG : NB, my_g = aw >= 0 ? aw - my_tb * PNG : 0;
   const bool pinned = aw >= 0 && my_tb < NB;
+  const int w_tab = NB > 1 ? 1 : 0, w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
 
   if (aw < 0) {
     const int d = TURN + 1;
     if (d < n) {
-      pf_prepare_tables<NT>(sm, T, A.scale, d, tid);
+      pf_prepare_tables<NT>(sm, d, tid);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       if (d > TURN) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
-        if (i >= 1 && i <= ncell) {
+        if (!(DRNA_SKIP & 16) && i >= 1 && i <= ncell) {
           const double aG = (sm.partG[par][0][tid] + sm.partG[par][1][tid]) + sm.partG[par][2][tid];
           const double aK = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
           const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
@@ -308,14 +315,22 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           QM[d * ld + i] = m1 + aK + U;
         }
       }
-      if (k + 1 < n) {
-        pf_prepare_tables<NT>(sm, T, A.scale, k + 1, tid);
-        const int cnt = PL[(k + 1) * ld + ld - 1];
-        if (tid < cnt) sm.plist[(k + 1) & 1][tid] = PL[(k + 1) * ld + tid];
-        if (tid == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
+      // side jobs of the step, one finalize wave each (when there are that many): tower table of diagonal k+1,
+      // pairable list of diagonal k+1, exterior column j = k-3 (its cells were stored in step <= k-3 and drained by
+      // that step's barrier)
+      if (!(DRNA_SKIP & 32) && k + 1 < n) {
+        if (wave == w_tab) pf_prepare_tables<NT>(sm, k + 1, lane);
+        if (wave == w_pl) {
+          const int32_t* row = PL + (k + 1) * ld;
+          const int cnt = row[ld - 1];
+          const int p0 = row[lane], p1 = row[lane + WAVE], p2 = row[lane + 2 * WAVE], p3 = row[min(lane + 3 * WAVE, ld - 1)];
+          int* dst = sm.plist[(k + 1) & 1];
+          dst[lane] = p0; dst[lane + WAVE] = p1; dst[lane + 2 * WAVE] = p2;
+          if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = p3;
+          if (lane == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
+        }
       }
-      // exterior column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier)
-      if (wave == 0 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
+      if (!(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
       STAMP(4);
       __syncthreads();
       STAMP(3);
