@@ -22,7 +22,6 @@
 namespace drna {
 
 constexpr int MFE_FAST_NMAX = 200;
-constexpr int EC = 4;              // pairable cells per bulge / 1xn work item
 constexpr int GSLOTS = 10;         // register-resident running minima per lane and parity (28 residues over >= 3 waves)
 
 template <int NT>
@@ -295,14 +294,28 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     int GE[GSLOTS], GO[GSLOTS];
 #pragma unroll
     for (int r = 0; r < GSLOTS; r++) { GE[r] = INF; GO[r] = INF; }
-    // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
-    // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
-    const bool b_on = lane < 58, o_on = lane < 54;
-    const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
-    const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
-    const int b_L = keep_i32(T.bulge[b_on ? b_s : 30]);
-    const int o_nl = o_s - 1;
-    const int o_L = keep_i32(T.interior[o_on ? o_nl + 1 : 30] + min(max_ninio, (o_nl - 1) * ninio));
+    // E: a 16-lane row works on one pairable cell; lane l of the row takes the eight loop shapes x = 16 k + l:
+    // k < 4 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), k >= 4 1xn loops (y = x-64 < 27: (1,u) u = y+3;
+    // y < 54: (u,1) u = y-24); the remaining slots are padding.  Packed per shape: s = u1+u2 | u1 << 8 | size term << 16.
+    int e_shape[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int x = (k & 3) * 16 + (lane & 15);
+      int s_, u1_, L_;
+      if (k < 4) {
+        const bool on = x < 58;
+        u1_ = (x < 29 || !on) ? 0 : x - 27;
+        s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
+        L_ = on ? T.bulge[s_] : 0x3fff;
+      } else {
+        const bool on = x < 54;
+        u1_ = (x < 27 || !on) ? 1 : x - 24;
+        s_ = !on ? 4 : x < 27 ? x + 4 : x - 23;
+        const int nl = s_ - 1;
+        L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
+      }
+      e_shape[k] = keep_i32(s_ | (u1_ << 8) | (L_ << 16));
+    }
     const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
 
     for (int k = TURN + 1; k <= n; k++) {
@@ -326,11 +339,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
         // pairable cells for the 112 bulge / 1xn shapes (E), then three groups of fixed small shapes per 64
         // pairable cells (X).  Minima are order-free, so who takes what does not matter.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + EC - 1) / EC,
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2,
                   nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
-        const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
-        const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-        const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
           if (it < nK) {
@@ -368,30 +378,36 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
             if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
           } else if (it < nK + nE) {
-            // ---- E: EC pairable cells per item, the 112 bulge / 1xn shapes over the lanes.  The cells' chains (list entry
-            // -> ring words -> table gathers -> wave minimum) are independent, so they overlap: an item is bound by
-            // LDS round-trip latency, not by issue.
-            const int q = EC * (it - nK);
-            int pe[EC], v[EC];
+            // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shapes in registers, the
+            // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer
+            const int q = 4 * (it - nK) + (lane >> 4);
+            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+            const int i0 = pe & 255, ij = pe >> 8;
+            int w[8];
+            bool ok[8];
 #pragma unroll
-            for (int c = 0; c < EC; c++) pe[c] = sm.plist[par][as_vector(q + c < pcnt ? q + c : q)];
-            int wb[EC], wo[EC];
+            for (int k = 0; k < 8; k++) {
+              const int dp = d - 2 - (e_shape[k] & 255);         // diagonal of the inner pair
+              ok[k] = dp > TURN;
+              w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 255) + i0];
+            }
+            const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij];
+            int v = INF;
 #pragma unroll
-            for (int c = 0; c < EC; c++) { wb[c] = sm.wring[b_off + (pe[c] & 255)]; wo[c] = sm.wring[o_off + (pe[c] & 255)]; }
-#pragma unroll
-            for (int c = 0; c < EC; c++) {
-              const int ij = pe[c] >> 8;
-              const int eb = (wb[c] >> 8) + b_L + ((ij >> 4) > 2 ? TermAU : 0);
-              const int eo = (wo[c] >> 8) + o_L + sm.mm1np[wo[c] & 127] + sm.mm1n[ij];
-              v[c] = min(b_ok ? eb : INF, o_ok ? eo : INF);
+            for (int k = 0; k < 4; k++) {
+              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + outer_b;
+              v = min(v, ok[k] ? e : INF);
             }
 #pragma unroll
-            for (int c = 0; c < EC; c++) v[c] = wave_min_i32_lane63(v[c]);
-            if (lane == WAVE - 1) {
-#pragma unroll
-              for (int c = 0; c < EC; c++)
-                if (q + c < pcnt && v[c] < HALF) atomicMin(&sm.accI[par][(pe[c] & 255) + slot0], v[c]);
+            for (int k = 4; k < 8; k++) {
+              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + sm.mm1np[w[k] & 127] + outer_o;
+              v = min(v, ok[k] ? e : INF);
             }
+            v = dpp_min_i32<0x111, 0xF>(v);
+            v = dpp_min_i32<0x112, 0xF>(v);
+            v = dpp_min_i32<0x114, 0xF>(v);
+            v = dpp_min_i32<0x118, 0xF>(v);
+            if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
           } else {
             // ---- X: one group of fixed small shapes for 64 pairable cells (lane = compacted cell)
             const int xi = it - nK - nE;
