@@ -44,6 +44,8 @@ struct PfFastSmem {
   double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
+  double eWb[WAVE], eWo[WAVE];    // bulge / 1xn size weights of the shape each lane owns in the E items
+  double xc[8];                   // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items)
   double tw_as[32], tw_W[32];     // by total size s of a generic loop: asymmetry-independent factors (see pf_prepare_tables)
   double tw_d[2][32][3];          // per residue: asymmetry factor, keep factor (0 forgets the previous tenant), size factor
   int tw_i[2][32][2];             // per residue: byte offsets A, B into qbi
@@ -179,6 +181,17 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
+  if (tid < WAVE) {
+    // E items: lane l owns bulge (0,u) u = l+2 (l < 29) or (u,0) u = l-27 (l < 58), and 1xn loop (1,u) u = l+3 (l < 27) or
+    // (u,1) u = l-24 (l < 54); idle lanes keep a finite weight (their terms are switched off in the sweep)
+    const int bs = tid >= 58 ? 2 : tid < 29 ? tid + 2 : tid - 27, os = tid >= 54 ? 4 : tid < 27 ? tid + 4 : tid - 23;
+    sm.eWb[tid] = T.bulge[bs] * A.scale[bs + 2];
+    sm.eWo[tid] = T.interior[os] * T.eninio[os - 2] * A.scale[os + 2];
+  }
+  if (tid == 0) {
+    sm.xc[0] = T.bulge[1] * A.scale[3]; sm.xc[1] = T.interior[5] * T.eninio[1] * A.scale[7];
+    sm.xc[2] = A.scale[4]; sm.xc[3] = A.scale[5]; sm.xc[4] = A.scale[6];
+  }
   for (int k = tid; k < 32; k += NT) {
     sm.tw_as[k] = k >= 4 && k <= 30 ? T.eninio[k - 4] : 0.0;
     sm.tw_W[k] = k >= 6 && k <= 30 ? T.interior[k] * A.scale[k + 2] : 0.0;
@@ -348,12 +361,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     const bool b_on = lane < 58, o_on = lane < 54;
     const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
     const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
-    const double b_W = keep_f64(T.bulge[b_s] * A.scale[b_s + 2]);
-    const int o_nl = o_s - 1;
-    const double o_W = keep_f64(T.interior[o_nl + 1] * T.eninio[o_nl - 1] * A.scale[o_s + 2]);
     // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
-    const double x_b1 = keep_f64(T.bulge[1] * A.scale[3]), x_23 = keep_f64(T.interior[5] * T.eninio[1] * A.scale[7]);
-    const double sc4 = keep_f64(A.scale[4]), sc5 = keep_f64(A.scale[5]), sc6 = keep_f64(A.scale[6]);
 
     // QM and QM1 (adjacent tables) through one buffer descriptor
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
@@ -427,6 +435,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
             const int f10 = sm.info[b_off + i1], f11 = sm.info[o_off + i1];
             const double r00 = sm.rbul[f00], r01 = sm.r1n[f01], r10 = sm.rbul[f10], r11 = sm.r1n[f11];
             const double m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+            const double b_W = sm.eWb[lane], o_W = sm.eWo[lane];
             double v0 = (b_ok ? w00 * r00 * b_W : 0.0) * ((ij0 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w01 * r01 * o_W : 0.0) * m0;
             double v1 = (b_ok ? w10 * r10 * b_W : 0.0) * ((ij1 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w11 * r11 * o_W : 0.0) * m1;
             v0 = wave_total_f64_lane63(v0);
@@ -455,8 +464,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
                 f[shp] = dp > TURN ? sm.info[off] : 0;
               }
               sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
-              sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * x_b1;
-              sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sc4;
+              sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * sm.xc[as_vector(0)];
+              sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sm.xc[as_vector(2)];
             } else if (grp == 1) {
               // (1,2) (2,1) (2,2): tables in global memory (L2)
               const int dpa = d - 5, dpb = d - 6;
@@ -466,14 +475,14 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
               const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
               const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
               const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
-              sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sc5 + wc * sm.rinv[fc] * gc * sc6;
+              sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sm.xc[as_vector(3)] + wc * sm.rinv[fc] * gc * sm.xc[as_vector(4)];
             } else {
               // (2,3) (3,2)
               const int dp = d - 7;
               const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
               const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
               const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
-              sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * x_23;
+              sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * sm.xc[as_vector(1)];
             }
             if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
           }
