@@ -590,7 +590,7 @@ extern "C" int drna_metropolis_batch(int R, const double* score_o, const double*
   return DRNA_OK;
 }
 
-#ifdef DRNA_STAMPS
+#if defined(DRNA_STAMPS) || defined(DRNA_STAMPS_API)
 // diagnostic build only: copy `count` int32 of the MFE workspace starting at int32 offset `off`
 extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, int32_t* out) {
   if (!e || !out) return DRNA_ERR_ARG;

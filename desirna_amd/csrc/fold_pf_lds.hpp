@@ -350,6 +350,9 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
 #ifdef DRNA_STAMPS
       if (blockIdx.x == 0 && tid == 0) dbg[256 + k] = st_acc[4];
 #endif
+#ifdef DRNA_STEPCLK
+      if (blockIdx.x == DRNA_STEPCLK - 1 && tid == 0) reinterpret_cast<long long*>(base + 5 * tab)[k] = clock64();
+#endif
     }
   } else {
     // ================= sweep waves: diagonal d = k at step k
@@ -365,7 +368,6 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
 
     // QM and QM1 (adjacent tables) through one buffer descriptor
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
-    const int astep = 32 * ld, cstep = 32 * ld - 32;
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -387,7 +389,11 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
         // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
         // not depend on which wave takes it.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+        // K items per 32-cell block: 4 once a single block is left (the operand offsets of the wider stride stay inside the
+        // descriptor only for ld >= 48)
+        const int kssh = (ncell <= 32 && ld >= 48) ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
+        const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
+        const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
                   nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
         const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
         const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
@@ -398,17 +404,20 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
             // ---- K: multiloop sum D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j] for 32 cells x 4 interleaved split-point
             // groups: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
             // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
-            const int g = lane >> 4, cl = lane & 15;
-            int i = (it << 5) + 2 * cl + 1;
+            // When few blocks are left (late diagonals: few cells, long sums) a block's split points are dealt to KS = 2 or 4
+            // items, so that no wave walks the whole sum as one chain of dependent L2 round trips while the others idle;
+            // the rows of such an item are folded inside the wave so that the four slices still suffice.
+            const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+            int i = ((it >> kssh) << 5) + 2 * cl + 1;
             const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
             i = act0 ? i : 1;
             double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
             int tt = TURN + 1 + g;
             // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
-            // a step of 4 in tt moves them by +32 ld and -(32 ld - 32) bytes
+            // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
             int vA = (tt * ld + i) * 8;
-            int vC = (int)tab * 8 + ((d - tt - 13) * ld + i + tt + 13) * 8;          // operand of tt + 12
-            for (; tt + 12 <= d - TURN - 2; tt += 16) {
+            int vC = (int)tab * 8 + ((d - tt - 1 - 3 * KG) * ld + i + tt + 1 + 3 * KG) * 8;          // operand of tt + 3 KG
+            for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
               const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
               const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vC, 2 * cstep);
               const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vC, cstep);
@@ -417,13 +426,27 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
               p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
               p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
             }
-            for (; tt <= d - TURN - 2; tt += 4) {
+            for (; tt <= d - TURN - 2; tt += KG) {
               const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
               p0 += a0.x * c0.x; q0 += a0.y * c0.y;
               vA += astep; vC -= cstep;
             }
-            if (act0) sm.partK[par][g][i + slot0] = p0 + p1;
-            if (act1) sm.partK[par][g][i + 1 + slot0] = q0 + q1;
+            double v0 = p0 + p1, v1 = q0 + q1;
+            int slice = lane >> 4;
+            bool writer = true;
+            if (kssh >= 1) {                       // rows 0+1 and 2+3
+              v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+              slice = (it & (KS - 1)) * (4 >> kssh) + (lane >> 5);
+              writer = (lane & 16) == 0;
+            }
+            if (kssh == 2) {                       // all four rows
+              v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+              writer = lane < 16;
+            }
+            if (writer) {
+              if (act0) sm.partK[par][slice][i + slot0] = v0;
+              if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
+            }
           } else if (it < nK + nE) {
             const int q = 2 * (it - nK);
             const bool two = q + 1 < pcnt;
