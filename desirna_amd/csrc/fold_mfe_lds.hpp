@@ -44,6 +44,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
+  int eshape[128];               // bulge / 1xn shape slots of the E items: s = u1+u2 | u1 << 8 | size term << 16
   int tw_L[32];                  // generic interior size term by total loop size s (INF below 6)
   int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
 };
@@ -185,6 +186,26 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   for (int k = tid; k <= n; k += NT) { sm.hpl[k] = A.hp_len[k]; sm.rowoff[k] = k >= TURN + 1 ? fml_off(k, n) : 0; }
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
+  for (int x = tid; x < 128; x += NT) {
+    // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l:
+    // slots < 64 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3;
+    // y < 54: (u,1) u = y-24); the remaining slots are padding with an unreachable size term
+    int s_, u1_, L_;
+    if (x < 64) {
+      const bool on = x < 58;
+      u1_ = (x < 29 || !on) ? 0 : x - 27;
+      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
+      L_ = on ? T.bulge[s_] : 0x3fff;
+    } else {
+      const int y = x - 64;
+      const bool on = y < 54;
+      u1_ = (y < 27 || !on) ? 1 : y - 24;
+      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
+      const int nl = s_ - 1;
+      L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
+    }
+    sm.eshape[x] = s_ | (u1_ << 8) | (L_ << 16);
+  }
   for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
   for (int k = tid; k < 64; k += NT) sm.stackp[k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
   for (int k = tid; k < 1024; k += NT) sm.int11p[k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
@@ -294,28 +315,6 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     int GE[GSLOTS], GO[GSLOTS];
 #pragma unroll
     for (int r = 0; r < GSLOTS; r++) { GE[r] = INF; GO[r] = INF; }
-    // E: a 16-lane row works on one pairable cell; lane l of the row takes the eight loop shapes x = 16 k + l:
-    // k < 4 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), k >= 4 1xn loops (y = x-64 < 27: (1,u) u = y+3;
-    // y < 54: (u,1) u = y-24); the remaining slots are padding.  Packed per shape: s = u1+u2 | u1 << 8 | size term << 16.
-    int e_shape[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int x = (k & 3) * 16 + (lane & 15);
-      int s_, u1_, L_;
-      if (k < 4) {
-        const bool on = x < 58;
-        u1_ = (x < 29 || !on) ? 0 : x - 27;
-        s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
-        L_ = on ? T.bulge[s_] : 0x3fff;
-      } else {
-        const bool on = x < 54;
-        u1_ = (x < 27 || !on) ? 1 : x - 24;
-        s_ = !on ? 4 : x < 27 ? x + 4 : x - 23;
-        const int nl = s_ - 1;
-        L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
-      }
-      e_shape[k] = keep_i32(s_ | (u1_ << 8) | (L_ << 16));
-    }
     const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
 
     for (int k = TURN + 1; k <= n; k++) {
@@ -383,8 +382,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             const int q = 4 * (it - nK) + (lane >> 4);
             const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
             const int i0 = pe & 255, ij = pe >> 8;
-            int w[8];
+            int w[8], e_shape[8];
             bool ok[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e_shape[k] = sm.eshape[k * 16 + (lane & 15)];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
               const int dp = d - 2 - (e_shape[k] & 255);         // diagonal of the inner pair
