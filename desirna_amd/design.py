@@ -261,6 +261,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
         cur[k].get_replica_num(r + 1)
         cur[k].get_temp_shelf(temps[r])
     best = min(cur, key=lambda s: (s.mcc, s.scoring_function)) if cur else None
+    simulation_data = [dict(vars(s)) for s in cur]            # reference DesiRNA.py:353: one record per replica and exchange step
     stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=len(local))
     t_start = time.time()
     global_step = 0
@@ -304,15 +305,18 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
         stats["rej_re"] += rej
         for k, r in enumerate(local):
             cur[k].get_temp_shelf(new_temps[r])
+            cur[k].get_sim_step(global_step)
+        simulation_data += [dict(vars(s)) for s in cur]       # reference DesiRNA.py:375
         if progress:
             progress(global_step, best, stats)
     stats["elapsed_s"] = time.time() - t_start
-    return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step}
+    return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step,
+            "simulation_data": simulation_data}
 
 
 def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                     scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-                    device=0, engine=None):
+                    device=0, engine=None, keep_records=True):
     """Same loop as :func:`run_design` with the per-replica host work in native code and no per-step Python objects:
     proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.
     Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
@@ -367,6 +371,24 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     best = dict(sequence=cur[k0].tobytes().decode(), mfe_ss=cur_ss[k0].tobytes().decode(), mcc=float(cur_mcc[k0]),
                 scoring_function=float(cur_score[k0]), Epf=float(cur_epf[k0]), edesired=float(cur_ed[k0]))
     stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=R)
+
+    def records(step_no):
+        out = []
+        for r in range(R):
+            sc = es.ScoreSeq(cur[r].tobytes().decode())
+            sc.scoring_function = float(cur_score[r])
+            sc.get_replica_num(r + 1)
+            sc.get_temp_shelf(float(temps[r]))
+            sc.get_sim_step(step_no)
+            sc.get_Epf(float(cur_epf[r]))
+            sc.get_edesired(float(cur_ed[r]))
+            sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
+            sc.mcc = float(cur_mcc[r])
+            sc.get_mfe_ss(cur_ss[r].tobytes().decode())
+            out.append(dict(vars(sc)))
+        return out
+
+    simulation_data = records(0) if keep_records else []
     t_start = time.time()
     step = 0
     solved = best["mcc"] == 0.0
@@ -404,8 +426,10 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         temps = np.array(new_temps, dtype=np.float64)
         stats["acc_re"] += a
         stats["rej_re"] += rj
+        if keep_records:
+            simulation_data += records(step)
     stats["elapsed_s"] = time.time() - t_start
-    return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step}
+    return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data}
 
 
 def main(argv=None):
@@ -424,11 +448,27 @@ def main(argv=None):
     ap.add_argument("-seed", "--seed_number", type=int, default=0, dest="in_seed")
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
     ap.add_argument("--python-host", action="store_true", help="per-replica Python host loop instead of the native batched one")
+    ap.add_argument("-o", "--outdir", default=None, help="write the reference's result files (_results.csv, _traj.csv, "
+                    "_stats, _best_str, fasta files) into this directory")
     a = ap.parse_args(argv)
     inp = read_input(a.name)
     res = (run_design if a.python_host else run_design_fast)(inp, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
                      t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
                      seed=a.in_seed, stop_when_solved=a.sws == "on")
+    if a.outdir:
+        import os
+        from . import outputs
+        os.makedirs(a.outdir, exist_ok=True)
+        sf = es.parse_scoring_functions(a.scoring_f)
+        pks = "on" if set(inp.sec_struct) - set(".()&") else "off"
+        outname = outputs.get_outname(os.path.basename(a.name), a.replicas, a.exchange, a.timlim, pks, "off", a.t_min, a.t_max,
+                                      "1999", sf, "off", "off", a.pm)
+        st = res["stats"]
+        stats = SimpleNamespace(step=st["acc_mc"] + st["rej_mc"], global_step=res["steps"], acc_mc_step=st["acc_mc"],
+                                acc_mc_better_e=st["acc_mc_better"], rej_mc_step=st["rej_mc"], acc_re_step=st["acc_re"],
+                                rej_re_step=st["rej_re"])
+        outputs.write_all(res["simulation_data"], inp.name, os.path.basename(a.name), outname, stats, st["elapsed_s"], a.timlim,
+                          time.strftime("%Y%m%d.%H%M%S"), directory=a.outdir)
     b = res["best"]
     print("Design solved succesfully!" if res["solved"] else "Design not solved.")
     print(b.sequence)

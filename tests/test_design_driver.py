@@ -235,3 +235,23 @@ def test_alt_structure_design_on_gpu():
     _snake_invariants(p, res2["best"].sequence)
     sc = res2["best"]
     assert abs(sc.scoring_function - (sc.edesired_minus_Epf + sc.edesired2_minus_Epf)) < 1e-9
+
+
+def test_design_run_writes_reference_result_files(oracle, tmp_path):
+    """A short run through the Python driver, then the reference's result files (formats pinned byte-for-byte in
+    tests/test_host_golden.py): one record per replica per exchange step, header = vars(ScoreSeq) order."""
+    from desirna_amd import outputs
+    inp = SimpleNamespace(name="ete1", sec_struct=ETE1, seq_restr="N" * len(ETE1), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design(inp, replicas=4, exchange=10, steps=3, seed=3,
+                            scorer=OracleScorer(oracle, ETE1, parse_scoring_functions("Ed-Epf:1.0")))
+    assert len(res["simulation_data"]) == 4 * (3 + 1)
+    st = res["stats"]
+    stats = SimpleNamespace(step=st["acc_mc"] + st["rej_mc"], global_step=res["steps"], acc_mc_step=st["acc_mc"],
+                            acc_mc_better_e=st["acc_mc_better"], rej_mc_step=st["rej_mc"], acc_re_step=st["acc_re"],
+                            rej_re_step=st["rej_re"])
+    top, ok = outputs.write_all(res["simulation_data"], "ete1", "ete1.txt", "out", stats, 1.0, 60, "NOW", directory=str(tmp_path))
+    hdr = open(tmp_path / "out_traj.csv").readline().strip().split(",")
+    assert hdr[:5] == ["sequence", "scoring_function", "replica_num", "temp_shelf", "sim_step"]
+    assert ok == res["solved"] and top[0]["mcc"] == min(r["mcc"] for r in res["simulation_data"])
+    assert open(tmp_path / "out_best_str").read().startswith(">ete1,%s," % ok)

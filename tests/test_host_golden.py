@@ -120,3 +120,25 @@ def test_proposals_same_position_and_draws():
             assert mine[pos] == ref[pos]                          # first letter: sorted list, deterministic
             assert mine[j] in CAN_PAIR[mine[pos]] and ref[j] in CAN_PAIR[ref[pos]]
     assert n_exact > len(GOLD["proposals"]) // 2
+
+
+def test_output_files_byte_for_byte():
+    """_traj.csv, _multifasta.fas, _best_fasta.fas, _results.csv, _best_str, _stats and the output name, against what the
+    reference's own writers produced from the same records."""
+    from desirna_amd import outputs
+    g = GOLD["outputs"]
+    sim = [dict((k, v) for k, v in r) for r in g["simulation_data"]]      # key order = vars(ScoreSeq)
+    traj = outputs.sort_trajectory(sim)
+    assert outputs.trajectory_csv_text(traj) == g["files"]["_traj.csv"]
+    assert outputs.multifasta_text(traj, "toy.txt", "NOW") == g["files"]["_multifasta.fas"]
+    assert outputs.best_fasta_text(sim, "toy.txt", "NOW", 10) == g["files"]["_best_fasta.fas"]
+    res = outputs.sort_and_filter(sim, 10)
+    assert outputs.results_csv_text(res) == g["files"]["_results.csv"]
+    txt, ok = outputs.check_if_design_solved(res[:10], "Toy")
+    assert (txt, ok) == (g["best_str"], g["solved"])
+    st = SimpleNamespace(**g["stats"])
+    assert outputs.stats_text(st, res, ok, g["finish_time"], "toyout", 60) == g["stats_txt"]
+    c = g["outname_case"]
+    assert outputs.get_outname(c["infile"], c["replicas"], c["RE_attempt"], c["timlim"], c["pks"], c["acgu_percentages"], c["T_min"],
+                               c["T_max"], c["param"], [tuple(x) for x in c["scoring_f"]], c["oligo"], c["dimer"],
+                               c["point_mutations"]) == g["outname"]

@@ -17,6 +17,8 @@ Recorded:
   problems         per example input: pairs, letters_allowed (sorted), snake graphs/states, excluded alt pairs
                                                                                     utils/sequence_utils.py:120-525
   initial          initial_sequence_generator with random.seed(k)                  :686-763
+  outputs          the reference's writers (_traj.csv, _multifasta.fas, _best_fasta.fas, _results.csv, _best_str, _stats text,
+                   get_outname) on a synthetic simulation_data list               utils/stats_inputs_outputs.py:304-669
   proposals        mutate_sequence with random.seed(k) on fixed (sequence, mfe_ss, temp_shelf): proposed sequence
                    and the value of random.random() right after (pins the number of draws)   :926-1136
 """
@@ -169,6 +171,56 @@ def main():
                     G["proposals"].append({"input": name, "variant": vname, "sequence": base_seq, "mfe_ss": ss,
                                            "shelf": shelf, "n_shelves": R, "seed": 1000 * shelf + k,
                                            "proposed": recorded["seq"], "next_random": random.random()})
+    # ---- output files: reference writers run on a synthetic simulation_data list (records = vars(ScoreSeq))
+    rng = random.Random(77)
+    sim = []
+    structs = ["((((....))))", "(((......)))", "............", "((((....))))"]
+    for k in range(14):
+        sc = es.ScoreSeq(sequence="".join(rng.choice("ACGU") for _ in range(12)) if k % 5 else "GGGGAAAACCCC")
+        sc.get_replica_num(k % 4 + 1)
+        sc.get_temp_shelf(round(10 + 46.667 * (k % 4), 3))
+        sc.get_sim_step(k // 4)
+        sc.get_Epf(-rng.uniform(1, 9))
+        sc.get_mfe_ss(structs[k % 4])
+        sc.get_edesired(-rng.uniform(0, 8))
+        sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
+        sc.get_mcc(1.0 if k % 3 == 0 else round(rng.uniform(0, 1), 3))
+        sc.get_precision(round(rng.uniform(0, 1), 3))
+        sc.get_recall(round(rng.uniform(0, 1), 3))
+        sc.scoring_function = sc.edesired_minus_Epf
+        sim.append(vars(sc))
+    opts = types.SimpleNamespace(oligo="off", dimer="off", subopt="off", num_results=10, infile="toy.txt", outname="toyout", timlim=60)
+    inp0 = types.SimpleNamespace(name="Toy", sec_struct="((((....))))", graphs=None)
+    st = sio.Stats()
+    st.global_step, st.step, st.acc_mc_step, st.acc_mc_better_e, st.rej_mc_step, st.acc_re_step, st.rej_re_step = 3, 300, 211, 150, 89, 4, 5
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        import copy
+        data = copy.deepcopy(sim)
+        traj = sio.sort_trajectory(data)
+        sio.generate_trajectory_csv(traj, opts.outname)
+        sio.generate_multifasta(traj, opts, "NOW")
+        sio.generate_best_fasta(data, opts, "NOW")
+        res = sio.sort_and_filter_simulation_data(data, opts, inp0)
+        sio.generate_csv_from_data(res, opts.outname)
+        txt, ok = sio.check_if_design_solved(res[:10], inp0, opts)
+        stats_txt = sio.generate_simulation_stats_text(st, res, ok, 83.4, opts)
+        files = {}
+        for suffix in ("_traj.csv", "_multifasta.fas", "_best_fasta.fas", "_results.csv"):
+            with open(opts.outname + suffix, newline="") as fh:
+                files[suffix] = fh.read()
+    finally:
+        os.chdir(cwd)
+    o2 = types.SimpleNamespace(infile="Standard_design_input.txt", replicas=10, RE_attempt=100, timlim=60, pks="off",
+                               acgu_percentages="off", T_min=10, T_max=150, param="1999", scoring_f=[("Ed-Epf", 1.0)],
+                               oligo="off", dimer="off", point_mutations="on")
+    G["outputs"] = {"simulation_data": [[[k, v] for k, v in r.items()] for r in sim],   # key order = vars(ScoreSeq) = CSV header
+                     "files": files, "best_str": txt, "solved": bool(ok), "stats_txt": stats_txt,
+                    "stats": {"global_step": 3, "step": 300, "acc_mc_step": 211, "acc_mc_better_e": 150, "rej_mc_step": 89,
+                              "acc_re_step": 4, "rej_re_step": 5}, "finish_time": 83.4,
+                    "outname_case": {k: getattr(o2, k) for k in vars(o2)}, "outname": sio.get_outname(o2)}
     with open(out, "w") as fh:
         json.dump(G, fh, indent=0, sort_keys=True)
     print({k: (len(v) if hasattr(v, "__len__") else v) for k, v in G.items()})
