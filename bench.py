@@ -201,11 +201,11 @@ def main():
                        "replicas_per_gpu": R, "L": L, "exchange_every": args.exchange_every,
                        "threads_per_workgroup": eng.info()["threads_per_wg"]},
             "kernel_ms": {k: round(v, 4) for k, v in tk.items()},
-            "roofline": {"bound": "hbm", "kernel": "%s_kernel" % dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("%s_lds_kernel<1024>" if L <= 200 else "%s_kernel<1024>") % dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would idle at the barrier
             out["cpu_baseline"] = cpu_baseline(seqs, target)
             out["speedup_vs_cpu_all_cores"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))
