@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -58,6 +60,11 @@ struct drna_engine {
   double* d_edef = nullptr;
   hipEvent_t ev_o0 = nullptr, ev_o1 = nullptr, ev_o2 = nullptr;
   float timing_edef[2] = {0, 0};
+  // ragged batches: per-sequence descriptors (len, off, target, two index lists) and the structures' pair tables
+  int* d_rg = nullptr;
+  short* d_rpt = nullptr;
+  int* d_rpt_off = nullptr;
+  std::vector<int> rt_len;
   std::string err;
 };
 
@@ -146,7 +153,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   if (!e) return;
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
-                  e->d_ws_out, e->d_edef};
+                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -427,6 +434,180 @@ extern "C" int drna_ensemble_defect_batch(drna_engine* e, int R, int L, const ch
 extern "C" int drna_last_edef_timing(const drna_engine* e, float out[2]) {
   if (!e || !out) return DRNA_ERR_ARG;
   out[0] = e->timing_edef[0]; out[1] = e->timing_edef[1];
+  return DRNA_OK;
+}
+
+// ---------------------------------------------------------------- ragged batches (sequences of different lengths)
+
+extern "C" int drna_set_targets_ragged(drna_engine* e, int n_targets, const int32_t* lens, const char* targets) {
+  if (!e) return DRNA_ERR_ARG;
+  if (n_targets < 1 || !lens || !targets) { e->err = "drna_set_targets_ragged: bad argument"; return DRNA_ERR_ARG; }
+  std::vector<int> off(n_targets);
+  size_t total = 0, chars = 0;
+  for (int t = 0; t < n_targets; t++) {
+    if (lens[t] < 1 || lens[t] > e->max_L) { e->err = "drna_set_targets_ragged: structure length outside [1, max_L]"; return DRNA_ERR_ARG; }
+    off[t] = (int)total;
+    total += (size_t)lens[t] + 2;
+  }
+  std::vector<short> pt(total, 0);
+  std::vector<int> stk;
+  for (int t = 0; t < n_targets; t++) {
+    stk.clear();
+    const char* s = targets + chars;
+    short* p = pt.data() + off[t];
+    for (int i = 1; i <= lens[t]; i++) {
+      if (s[i - 1] == '(') stk.push_back(i);
+      else if (s[i - 1] == ')') {
+        if (stk.empty()) { e->err = "drna_set_targets_ragged: unbalanced ')'"; return DRNA_ERR_STRUCTURE; }
+        const int o = stk.back(); stk.pop_back();
+        p[o] = (short)i; p[i] = (short)o;
+      }
+    }
+    if (!stk.empty()) { e->err = "drna_set_targets_ragged: unbalanced '('"; return DRNA_ERR_STRUCTURE; }
+    chars += (size_t)lens[t];
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->d_rpt) { (void)hipFree(e->d_rpt); e->d_rpt = nullptr; }
+  if (e->d_rpt_off) { (void)hipFree(e->d_rpt_off); e->d_rpt_off = nullptr; }
+  HIP_TRY(upload(&e->d_rpt, pt.data(), pt.size()));
+  HIP_TRY(upload(&e->d_rpt_off, off.data(), off.size()));
+  e->rt_len.assign(lens, lens + n_targets);
+  return DRNA_OK;
+}
+
+extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, const char* seqs, const int32_t* target_of,
+                                 uint32_t flags, double* Epf, int32_t* Emfe, char* mfe_ss, int32_t* Ed) {
+  if (!e) return DRNA_ERR_ARG;
+  const bool want_pf = flags & DRNA_NEED_PF, want_mfe = flags & (DRNA_NEED_MFE | DRNA_NEED_PK),
+             want_pk = flags & DRNA_NEED_PK, want_ev = flags & DRNA_NEED_EVAL;
+  if (R < 1 || R > e->max_R || !lens || !seqs || (want_pf && !Epf) || (want_mfe && (!Emfe || !mfe_ss)) ||
+      (want_ev && (!Ed || !target_of))) {
+    e->err = "drna_score_ragged: bad argument (R within the engine's limit; output pointers for every requested flag)";
+    return DRNA_ERR_ARG;
+  }
+  // descriptors: len | off | target_of | index list of the LDS-resident kernels | index list of the general kernels
+  std::vector<int> h((size_t)5 * R);
+  int* off = h.data() + R;
+  size_t total = 0;
+  for (int r = 0; r < R; r++) {
+    if (lens[r] < 1 || lens[r] > e->max_L) { e->err = "drna_score_ragged: sequence length outside [1, max_L]"; return DRNA_ERR_ARG; }
+    h[r] = lens[r];
+    off[r] = (int)total;
+    total += (size_t)lens[r];
+    if (want_ev) {
+      const int t = target_of[r];
+      if (t < 0 || t >= (int)e->rt_len.size() || e->rt_len[t] != lens[r]) {
+        e->err = "drna_score_ragged: target_of[r] must name a structure of drna_set_targets_ragged() with the sequence's length";
+        return DRNA_ERR_ARG;
+      }
+      h[(size_t)2 * R + r] = t;
+    }
+  }
+  if (total > (size_t)e->max_R * e->max_L) { e->err = "drna_score_ragged: more nucleotides than max_R * max_L"; return DRNA_ERR_ARG; }
+  std::vector<int> order(R);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });   // longest first
+  const bool fast_ok = e->lds_path && e->nt == 1024;
+  int nA = 0, nB = 0;
+  int *idxA = h.data() + (size_t)3 * R, *idxB = h.data() + (size_t)4 * R;
+  for (int r : order) {
+    if (fast_ok && lens[r] <= MFE_FAST_NMAX && lens[r] <= PF_FAST_NMAX) idxA[nA++] = r;
+    else idxB[nB++] = r;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_rg) HIP_TRY(hipMalloc((void**)&e->d_rg, (size_t)5 * e->max_R * sizeof(int)));
+  HIP_TRY(hipMemcpy(e->d_rg, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_seqs, seqs, total, hipMemcpyHostToDevice));
+  if (want_ev && R > 0) {
+    if (!e->d_Ed) HIP_TRY(hipMalloc((void**)&e->d_Ed, (size_t)e->max_R * std::max(1, e->n_targets) * sizeof(int32_t)));
+  }
+  const int ld = e->max_L + 2;
+  for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
+  Ragged rg;
+  rg.len = e->d_rg; rg.off = e->d_rg + R;
+  const int* d_idxA = e->d_rg + (size_t)3 * R;
+  const int* d_idxB = e->d_rg + (size_t)4 * R;
+  HIP_TRY(hipEventRecord(e->ev_start, e->s_mfe));
+  HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_start, 0));
+  HIP_TRY(hipStreamWaitEvent(e->s_eval, e->ev_start, 0));
+  if (want_mfe) {
+    MfeArgs a;
+    a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = e->d_seqs; a.L = 0; a.ld = ld;
+    a.pk_rounds = want_pk ? 3 : 0;
+    a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
+    a.Emfe = e->d_Emfe; a.ss = e->d_ss; a.status = e->d_status;
+    a.rg = rg;
+    HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+    if (nB) {                                       // the long sequences first
+      a.rg.idx = d_idxB;
+      if (e->nt == 256) launch_mfe<256>(a, nB, e->s_mfe);
+      else if (e->nt == 512) launch_mfe<512>(a, nB, e->s_mfe);
+      else launch_mfe<1024>(a, nB, e->s_mfe);
+    }
+    if (nA) {
+      a.rg.idx = d_idxA;
+      hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_mfe, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+  }
+  if (want_pf) {
+    PfArgs a;
+    a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
+    a.seqs = e->d_seqs; a.L = 0; a.ld = ld;
+    a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
+    a.Epf = e->d_Epf; a.status = e->d_status + e->max_R;
+    a.rg = rg;
+    HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
+    if (nB) {
+      a.rg.idx = d_idxB;
+      if (e->nt == 256) launch_pf<256>(a, nB, e->s_pf);
+      else if (e->nt == 512) launch_pf<512>(a, nB, e->s_pf);
+      else launch_pf<1024>(a, nB, e->s_pf);
+    }
+    if (nA) {
+      a.rg.idx = d_idxA;
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_pf, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
+    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_p1, 0));
+  }
+  if (want_ev) {
+    EvalArgs a;
+    a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
+    a.seqs = e->d_seqs; a.pt = e->d_rpt; a.L = 0; a.n_targets = 1; a.Ed = e->d_Ed;
+    a.rg = rg; a.target_of = e->d_rg + (size_t)2 * R; a.pt_off = e->d_rpt_off;
+    HIP_TRY(hipEventRecord(e->ev_e0, e->s_eval));
+    hipLaunchKernelGGL(eval_kernel, dim3(R), dim3(WAVE), 0, e->s_eval, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_e1, e->s_eval));
+    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_e1, 0));
+  }
+  HIP_TRY(hipEventRecord(e->ev_end, e->s_mfe));
+  HIP_TRY(hipStreamSynchronize(e->s_mfe));
+  e->timing[0] = e->timing[1] = e->timing[2] = 0.f;
+  if (want_mfe) HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
+  if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
+  if (want_ev) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
+  HIP_TRY(hipEventElapsedTime(&e->timing[3], e->ev_start, e->ev_end));
+  for (int r = 0; r < R; r++) {
+    const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
+    const int st = sm != ST_OK ? sm : sp;
+    if (st == ST_OK) continue;
+    char buf[160];
+    snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
+                              : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"
+                                                  : "sequence %d: traceback could not reproduce a table value", r);
+    e->err = buf;
+    return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;
+  }
+  if (want_pf) HIP_TRY(hipMemcpy(Epf, e->d_Epf, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
+  if (want_mfe) {
+    HIP_TRY(hipMemcpy(Emfe, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, total, hipMemcpyDeviceToHost));
+  }
+  if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
   return DRNA_OK;
 }
 

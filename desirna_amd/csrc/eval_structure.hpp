@@ -22,6 +22,11 @@ struct EvalArgs {
   int L;
   int n_targets;
   int32_t* Ed;                  // R x n_targets (dcal/mol)
+  // ragged batch (one structure per sequence): lengths / offsets of the sequences, structure of each sequence and the
+  // offset of its pair table in pt (pair tables concatenated, L_t + 2 shorts each); grid = R, Ed = R values
+  Ragged rg;
+  const int* target_of = nullptr;
+  const int* pt_off = nullptr;
 };
 
 struct EvalSmem {
@@ -112,10 +117,13 @@ __device__ inline int eval_loop(const EvalSmem& sm, const EvalArgs& A, int i, in
 __global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
   __shared__ EvalSmem sm;
   const MfeTables& T = *A.T;
-  const int n = A.L, lane = threadIdx.x;
-  const int r = blockIdx.x / A.n_targets, k = blockIdx.x % A.n_targets;
-  const char* seq = A.seqs + (long long)r * n;
-  const short* pt = A.pt + (long long)k * (n + 2);
+  const int lane = threadIdx.x;
+  const bool ragged = A.rg.len != nullptr;
+  const int r = ragged ? blockIdx.x : blockIdx.x / A.n_targets, k = ragged ? 0 : blockIdx.x % A.n_targets;
+  if (ragged) A.L = A.rg.len[r];
+  const int n = A.L;
+  const char* seq = A.seqs + (ragged ? (long long)A.rg.off[r] : (long long)r * n);
+  const short* pt = ragged ? A.pt + A.pt_off[A.target_of[r]] : A.pt + (long long)k * (n + 2);
   bool bad = false;
   for (int x = lane; x < n; x += WAVE) {
     const int c = enc_nt(seq[x]);
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
   }
   e = wave_sum_i32(e);
   const unsigned long long anybad = __ballot(bad);
-  if (lane == 0) A.Ed[(long long)r * A.n_targets + k] = anybad ? INF_REF : e;
+  if (lane == 0) A.Ed[ragged ? (long long)r : (long long)r * A.n_targets + k] = anybad ? INF_REF : e;
 }
 
 }  // namespace drna

@@ -17,6 +17,15 @@ enum : int { TW_LIVE = 0, TW_BIRTH = 1, TW_KILL = 2, TW_DEAD = 3 };   // flag in
 // kernel status codes (per sequence)
 enum : int { ST_OK = 0, ST_BAD_CHAR = 1, ST_TRACEBACK = 2, ST_PF_RANGE = 3 };
 
+// Ragged batches (drna_score_ragged): sequences of different lengths in one launch.  idx maps a workgroup to its sequence
+// (the host sorts by length, longest first, and splits the list between the LDS-resident and the general kernels), len is
+// the sequence's length, off its byte offset in the concatenated sequence / structure buffers.  All null = uniform batch.
+struct Ragged {
+  const int* idx = nullptr;
+  const int* len = nullptr;
+  const int* off = nullptr;
+};
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

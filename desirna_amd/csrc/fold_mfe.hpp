@@ -33,6 +33,7 @@ struct MfeArgs {
   int32_t* Emfe;               // R  (dcal/mol, ViennaRNA INF convention not needed: always finite)
   char* ss;                    // R x L structure (pk-annotated if pk_rounds)
   int32_t* status;             // R
+  Ragged rg;                   // ragged batch: per-sequence length / offsets (L is then overwritten per workgroup)
 };
 
 template <int NLEN>
@@ -424,7 +425,9 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
 template <int NT>
 __global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
   __shared__ MfeSmem sm;
-  const int r = blockIdx.x;
+  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+  if (A.rg.len) A.L = A.rg.len[r];
+  const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;      // offset in seqs / ss
   const int n = A.L, ld = A.ld, tid = threadIdx.x;
   const MfeTables& T = *A.T;
   int32_t* base = A.ws + (long long)r * A.ws_stride;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
-  const char* seq = A.seqs + (long long)r * n;
+  const char* seq = A.seqs + so;
   for (int k = tid; k < n; k += NT) {
     const int c = enc_nt(seq[k]);
     if (c < 0) sm.flag = 1;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
   __syncthreads();
   if (sm.flag) {
     if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; }
-    for (int k = tid; k < n; k += NT) A.ss[(long long)r * n + k] = '.';
+    for (int k = tid; k < n; k += NT) A.ss[so + k] = '.';
     return;
   }
 
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(NT) void mfe_kernel(MfeArgs A) {
     __syncthreads();
     if (!more) break;
   }
-  for (int k = tid; k < n; k += NT) A.ss[(long long)r * n + k] = sm.sspk[k];
+  for (int k = tid; k < n; k += NT) A.ss[so + k] = sm.sspk[k];
   if (tid == 0) A.status[r] = status;
 }
 

@@ -30,6 +30,7 @@ struct PfArgs {
   int32_t* status;             // R
   double* q5out = nullptr;     // optional: q5[0..L] per sequence for the outside recursion (fold_outside.hpp)
   long long q5_stride = 0;     // doubles per sequence
+  Ragged rg;                   // ragged batch: per-sequence length / offsets (L is then overwritten per workgroup)
 };
 
 struct PfSmem {
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   constexpr int NW = NT / WAVE;
   const PfTables& T = *A.T;
   const Plan& P = *A.plan;
-  const int r = blockIdx.x;
+  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+  if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
-  const char* seq = A.seqs + (long long)r * n;
+  const char* seq = A.seqs + (A.rg.off ? (long long)A.rg.off[r] : (long long)r * n);
   for (int k = tid; k < n; k += NT) {
     const int c = enc_nt(seq[k]);
     if (c < 0) sm.flag = 1;

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
-  const int r = blockIdx.x;
+  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+  if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 6 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accX[0][0][0])[k] = 0.0;
   if (tid == 0) { sm.flag = 0; sm.q5[0] = 1.0; }
   __syncthreads();
-  const char* seq = A.seqs + (long long)r * n;
+  const char* seq = A.seqs + (A.rg.off ? (long long)A.rg.off[r] : (long long)r * n);
   for (int k = tid; k < n; k += NT) {
     const int c = enc_nt(seq[k]);
     if (c < 0) sm.flag = 1;

@@ -24,7 +24,7 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged")
 
 
 class EngineError(RuntimeError):
@@ -64,6 +64,10 @@ def load_library(path=None):
     L.drna_ensemble_defect_batch_device.argtypes = [vp, ci, ci, vp, vp, vp]
     L.drna_last_edef_timing.restype = ci
     L.drna_last_edef_timing.argtypes = [vp, vp]
+    L.drna_set_targets_ragged.restype = ci
+    L.drna_set_targets_ragged.argtypes = [vp, ci, vp, C.c_char_p]
+    L.drna_score_ragged.restype = ci
+    L.drna_score_ragged.argtypes = [vp, ci, vp, C.c_char_p, vp, u32, vp, vp, vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -150,6 +154,36 @@ class Engine:
         """Device-resident variant: arguments are raw device pointers (e.g. ``tensor.data_ptr()``).
         The caller must have made the inputs visible (``torch.cuda.synchronize()``) before the call."""
         self._check(self._L.drna_score_batch_device(self._h, R, L, d_seqs, flags, d_Epf, d_Emfe, d_ss, d_Ed))
+
+    def set_targets_ragged(self, structures):
+        """Structures of different lengths for :meth:`score_ragged` ('&' already removed)."""
+        lens = np.array([len(t) for t in structures], dtype=np.int32)
+        self._check(self._L.drna_set_targets_ragged(self._h, len(structures), lens.ctypes.data, "".join(structures).encode("ascii")))
+        self.n_ragged_targets = len(structures)
+
+    def score_ragged(self, seqs, target_of=None, flags=NEED_PF | NEED_MFE | NEED_EVAL):
+        """Sequences of DIFFERENT lengths in one call (BASELINE config 4: many puzzles x replicas).  target_of[r] is the index
+        (into :meth:`set_targets_ragged`) of the structure sequence r is evaluated on.  Returns dict(Epf, Emfe, mfe_ss, Ed[R])."""
+        R = len(seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.int32)
+        total = int(lens.sum())
+        if target_of is None:
+            flags &= ~NEED_EVAL
+        tof = np.ascontiguousarray(target_of, dtype=np.int32) if target_of is not None else None
+        Epf = np.zeros(R, dtype=np.float64) if flags & NEED_PF else None
+        want_mfe = flags & (NEED_MFE | NEED_PK)
+        Emfe = np.zeros(R, dtype=np.int32) if want_mfe else None
+        ss = np.zeros(total, dtype=np.uint8) if want_mfe else None
+        Ed = np.zeros(R, dtype=np.int32) if flags & NEED_EVAL else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.drna_score_ragged(self._h, R, lens.ctypes.data, "".join(seqs).encode("ascii"), ptr(tof), flags,
+                                              ptr(Epf), ptr(Emfe), ptr(ss), ptr(Ed)))
+        out_ss = None
+        if ss is not None:
+            b = ss.tobytes().decode("ascii")
+            offs = np.concatenate(([0], np.cumsum(lens)))
+            out_ss = [b[offs[k]:offs[k + 1]] for k in range(R)]
+        return {"Epf": Epf, "Emfe": Emfe, "mfe_ss": out_ss, "Ed": Ed}
 
     def ensemble_defect(self, seqs, want_bpp=False):
         """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
@@ -268,5 +302,5 @@ class HostKernels:
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
             raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged")
         return acc.astype(bool), bet.astype(bool)

@@ -97,6 +97,20 @@ int drna_score_batch_device(drna_engine *e, int R, int L, const char *d_seqs, ui
 int drna_last_timing(const drna_engine *e, float out[4]);
 
 /*
+ * Ragged batches: sequences of DIFFERENT lengths scored in one call -- BASELINE config 4 (the 100 Eterna100-V1 puzzles,
+ * 12 ... 400 nt, R replicas each) is one such batch instead of 100 calls.  The reference has no counterpart (it scores one
+ * sequence per call); per sequence the results are those of drna_score_batch.
+ *
+ * drna_set_targets_ragged: n_targets structures of lengths lens[t], concatenated without terminators.
+ * drna_score_ragged: R sequences of lengths lens[r], concatenated; target_of[r] names the structure E(target) is evaluated
+ * on (same length; needed with DRNA_NEED_EVAL only).  Outputs: Epf R doubles, Emfe R int32, mfe_ss concatenated like the
+ * sequences, Ed R int32 (ONE structure per sequence).  Sum of lengths <= max_R * max_L.
+ */
+int drna_set_targets_ragged(drna_engine *e, int n_targets, const int32_t *lens, const char *targets);
+int drna_score_ragged(drna_engine *e, int R, const int32_t *lens, const char *seqs, const int32_t *target_of,
+                      uint32_t flags, double *Epf, int32_t *Emfe, char *mfe_ss, int32_t *Ed);
+
+/*
  * Ensemble defect of R sequences against targets[0] (needs drna_set_targets with the same L): inside fill,
  * outside recursion, base-pair probabilities, then (1/L) * [ sum_{i unpaired in target} sum_j P(i,j)
  * + sum_{i paired with m in target} (1 - P(i,m)) ], '(' ')' pairs only.

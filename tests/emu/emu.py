@@ -21,6 +21,7 @@ def build():
     L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
+    L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_edef.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, ci, vp, vp, vp]
     return L
 
@@ -92,3 +93,19 @@ class Emu:
                              ed.ctypes.data, B.ctypes.data if bpp else None, st.ctypes.data)
         assert rc == 0
         return (ed, st, B) if bpp else (ed, st)
+
+    def ragged(self, seqs, lds=False):
+        """sequences of different lengths through one ragged 'launch' of the MFE and PF kernels"""
+        R = len(seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.int32)
+        offs = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32)
+        total = int(lens.sum())
+        E = np.zeros(R, dtype=np.int32)
+        ss = np.zeros(total, dtype=np.uint8)
+        Ep = np.zeros(R)
+        st = np.zeros(2 * R, dtype=np.int32)
+        rc = self.L.emu_ragged(self.blob.ctypes.data, self.blob.size, R, int(lens.max()), lens.ctypes.data, offs.ctypes.data,
+                               "".join(seqs).encode(), int(lds), E.ctypes.data, ss.ctypes.data, Ep.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        b = ss.tobytes().decode()
+        return E, [b[offs[k]:offs[k] + lens[k]] for k in range(R)], Ep, st

@@ -132,4 +132,39 @@ int emu_edef(const int32_t* blob, int n_int32, int R, int L, const char* seqs, c
   delete c;
   return 0;
 }
+
+// ragged batch: sequences of different lengths (concatenated) through the MFE and PF kernels of one "launch";
+// lds != 0 selects the LDS-resident kernels (256 threads: n <= 64).  ld = max_L + 2 for every sequence.
+int emu_ragged(const int32_t* blob, int n_int32, int R, int max_L, const int32_t* lens, const int32_t* offs, const char* seqs,
+               int lds, int32_t* Emfe, char* ss, double* Epf, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, max_L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = max_L + 2;
+  std::vector<int32_t> wsm((size_t)5 * ld * ld, 0);
+  const size_t pstride = (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8;
+  std::vector<double> wsp(pstride, 0.0);
+  for (int r = 0; r < R; r++) {
+    MfeArgs a;
+    a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data();
+    a.seqs = seqs; a.L = 0; a.ld = ld; a.pk_rounds = 0;
+    a.ws = wsm.data() - (size_t)r * 5 * ld * ld; a.ws_stride = (long long)5 * ld * ld;
+    a.Emfe = Emfe; a.ss = ss; a.status = status;
+    a.rg.len = lens; a.rg.off = offs;
+    PfArgs b;
+    b.T = &c->H.pf; b.plan = &c->H.plan; b.hp_w = c->H.hp_w.data(); b.scale = c->H.scale.data();
+    b.eMLb = c->H.eMLb.data(); b.seqs = seqs; b.L = 0; b.ld = ld;
+    b.ws = wsp.data() - (size_t)r * pstride; b.ws_stride = (long long)pstride;
+    b.Epf = Epf; b.status = status + R;
+    b.rg.len = lens; b.rg.off = offs;
+    if (lds) {
+      emu_launch(r, 256, [&]() { mfe_lds_kernel<256>(a); });
+      emu_launch(r, 256, [&]() { pf_lds_kernel<256>(b); });
+    } else {
+      emu_launch(r, 128, [&]() { mfe_kernel<128>(a); });
+      emu_launch(r, 128, [&]() { pf_kernel<128>(b); });
+    }
+  }
+  delete c;
+  return 0;
+}
 }

@@ -227,3 +227,74 @@ def test_edef_scoring_function(eng400, oracle):
     for s, r in zip(seqs, res):
         assert abs(r.ensemble_defect - oracle.ensemble_defect(s, target)) < EDEF_TOL
         assert r.scoring_function == r.ensemble_defect
+
+
+# ---- ragged batches (BASELINE config 4: the whole Eterna100-V1 set, 12 ... 400 nt, in ONE call)
+
+def test_ragged_eterna100_one_call(eng400, oracle, eterna_solutions):
+    """All 100 Eterna100-V1 solutions (reference eterna_benchmark results: MFE(sequence) == structure) as one ragged
+    batch: strings exact, Emfe == E(structure), Epf against the oracle for the short ones and against the uniform-call
+    path for a long one."""
+    from desirna_amd import engine as E
+    rows = eterna_solutions
+    seqs = [r["sequence"] for r in rows]
+    structs = [r["structure"] for r in rows]
+    eng400.set_targets_ragged(structs)
+    out = eng400.score_ragged(seqs, list(range(len(rows))))
+    for k, r in enumerate(rows):
+        assert out["mfe_ss"][k] == r["structure"], r["name"]
+        assert int(out["Emfe"][k]) == int(out["Ed"][k]), r["name"]
+    for k in sorted(range(len(rows)), key=lambda k: len(seqs[k]))[:25]:
+        assert abs(float(out["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE, rows[k]["name"]
+        assert int(out["Emfe"][k]) == oracle.mfe(seqs[k])[1]
+    k = max(range(len(rows)), key=lambda k: len(seqs[k]))
+    eng400.set_targets([structs[k]])
+    one = eng400.score_batch([seqs[k]])
+    assert float(one["Epf"][0]) == float(out["Epf"][k]) and int(one["Ed"][0, 0]) == int(out["Ed"][k])
+
+
+def test_ragged_config4_shape_matches_uniform_calls(eng400, eterna_solutions):
+    """Config 4 shape at reduced replica count (100 puzzles x 4 mutated replicas = 400 sequences, lengths 12 ... 400, sorted
+    longest-first inside the engine, LDS-resident and general kernels in the same call): every value equals what the
+    per-puzzle uniform call returns (bitwise: the kernels are the same, only the batching differs)."""
+    from desirna_amd import engine as E
+    big = E.Engine(max_R=400, max_L=400, device=0)
+    try:
+        rng = np.random.default_rng(404)
+        rows = eterna_solutions
+        seqs, tof = [], []
+        for p, r in enumerate(rows):
+            for _ in range(4):
+                s = list(r["sequence"])
+                for pos in rng.choice(len(s), size=min(3, len(s)), replace=False):
+                    s[pos] = "ACGU"[rng.integers(4)]
+                seqs.append("".join(s))
+                tof.append(p)
+        big.set_targets_ragged([r["structure"] for r in rows])
+        out = big.score_ragged(seqs, tof)
+        for p in (0, 17, 52, 68, 99):
+            big.set_targets([rows[p]["structure"]])
+            mine = [k for k in range(len(seqs)) if tof[k] == p]
+            ref = big.score_batch([seqs[k] for k in mine])
+            for a, k in enumerate(mine):
+                assert ref["mfe_ss"][a] == out["mfe_ss"][k]
+                assert float(ref["Epf"][a]) == float(out["Epf"][k])
+                assert int(ref["Emfe"][a]) == int(out["Emfe"][k]) and int(ref["Ed"][a, 0]) == int(out["Ed"][k])
+    finally:
+        big.close()
+
+
+def test_ragged_edges_and_errors(eng400, oracle):
+    from desirna_amd import engine as E
+    seqs = ["G", "GGGAAACCC", "ACGU", "GGGGGAAAAACCCCC", "A" * 201]
+    eng400.set_targets_ragged(["." * len(s) for s in seqs])
+    out = eng400.score_ragged(seqs, list(range(len(seqs))))
+    for k, s in enumerate(seqs):
+        assert (out["mfe_ss"][k], int(out["Emfe"][k])) == oracle.mfe(s)
+        assert int(out["Ed"][k]) == 0
+    with pytest.raises(E.EngineError) as ei:
+        eng400.score_ragged(["GGGAAACCC"], [0])            # structure 0 has length 1
+    assert ei.value.code == -1
+    with pytest.raises(E.EngineError) as ei:
+        eng400.score_ragged(["GGGANACCC"], None)
+    assert ei.value.code == -4

@@ -111,3 +111,16 @@ def test_outside_kernel_bpp_and_defect(emu, oracle, L, nt):
         oe, ob = oracle.ensemble_defect(s, target, want_bpp=True)
         assert abs(ed[k] - oe) < 1e-12, s
         assert np.abs(B[k] - ob).max() < 1e-12, s
+
+
+# ---- ragged batches: per-workgroup length / offsets (drna_score_ragged)
+
+@pytest.mark.parametrize("lds", [False, True])
+def test_ragged_lengths_in_one_launch(emu, oracle, lds):
+    rng = np.random.default_rng(77)
+    seqs = [_rand(rng, L) for L in (40, 1, 7, 23, 64, 5)]
+    E, ss, Ep, st = emu.ragged(seqs, lds=lds)
+    assert not st.any()
+    for k, s in enumerate(seqs):
+        assert (ss[k], int(E[k])) == oracle.mfe(s), s
+        assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s

@@ -33,4 +33,24 @@ run("config3_shape_R256", bench.load_target("eteV1_69.txt"), 256, E.NEED_MFE | E
 tg = bench.load_target("eteV1_53.txt")
 pk = list(tg)
 run("config5_L400_R128_pk_alt", tg, 128, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL | E.NEED_PK, alts=[tg, tg], reps=3)
+# config 4: the whole Eterna100-V1 set, 32 replicas per puzzle, one ragged call
+import csv
+rows = list(csv.DictReader(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "eterna_v1_solutions.csv"))))
+seqs, tof = [], []
+for p, r in enumerate(rows):
+    for _ in range(32):
+        s = list(r["sequence"])
+        for pos in rng.choice(len(s), size=min(3, len(s)), replace=False):
+            s[pos] = "ACGU"[rng.integers(4)]
+        seqs.append("".join(s))
+        tof.append(p)
+eng = E.Engine(max_R=len(seqs), max_L=400, device=0)
+eng.set_targets_ragged([r["structure"] for r in rows])
+for _ in range(2):
+    eng.score_ragged(seqs, tof)
+t = eng.last_timing()
+out["config4_eterna100_R32_ragged"] = {"sequences": len(seqs), "nucleotides": sum(len(s) for s in seqs), "mfe_ms": t["mfe"],
+                                       "pf_ms": t["pf"], "eval_ms": t["eval"], "total_ms": t["total"],
+                                       "folds_per_s": len(seqs) / (t["total"] * 1e-3), "workspace_GB": eng.info()["workspace_bytes"] / 1e9}
+eng.close()
 print(json.dumps(out, indent=1))
