@@ -228,9 +228,23 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   HIP_TRY(hipSetDevice(e->device));
   const int ld = L + 2;
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
-  HIP_TRY(hipEventRecord(e->ev_start, e->s_mfe));
-  HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_start, 0));
-  HIP_TRY(hipStreamWaitEvent(e->s_eval, e->ev_start, 0));
+  // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
+  // start; the partition function -- the longest kernel -- is enqueued first
+  if (want_pf) {
+    PfArgs a;
+    a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
+    a.seqs = d_seqs; a.L = L; a.ld = ld;
+    a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
+    a.Epf = d_Epf; a.status = e->d_status + e->max_R;
+    HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
+    if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
+    else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
+    else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
+    else launch_pf<1024>(a, R, e->s_pf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
+  }
   if (want_mfe) {
     MfeArgs a;
     a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = d_seqs; a.L = L; a.ld = ld;
@@ -246,22 +260,6 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
   }
-  if (want_pf) {
-    PfArgs a;
-    a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
-    a.seqs = d_seqs; a.L = L; a.ld = ld;
-    a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
-    a.Epf = d_Epf; a.status = e->d_status + e->max_R;
-    HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
-    else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
-    else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
-    else launch_pf<1024>(a, R, e->s_pf);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
-    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_p1, 0));
-  }
   if (want_ev) {
     EvalArgs a;
     a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
@@ -270,15 +268,17 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, e->s_eval, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_e1, e->s_eval));
-    HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_e1, 0));
   }
+  // join: the MFE stream waits for the other two, then marks the end
+  if (want_pf) HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_p1, 0));
+  if (want_ev) HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_e1, 0));
   HIP_TRY(hipEventRecord(e->ev_end, e->s_mfe));
   HIP_TRY(hipStreamSynchronize(e->s_mfe));
   e->timing[0] = e->timing[1] = e->timing[2] = 0.f;
   if (want_mfe) HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
   if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
   if (want_ev) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
-  HIP_TRY(hipEventElapsedTime(&e->timing[3], e->ev_start, e->ev_end));
+  HIP_TRY(hipEventElapsedTime(&e->timing[3], want_pf ? e->ev_p0 : want_mfe ? e->ev_m0 : e->ev_e0, e->ev_end));
   for (int r = 0; r < R; r++) {
     const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
     const int st = sm != ST_OK ? sm : sp;
