@@ -265,6 +265,154 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   long long st_last = clock64();
   long long* dbg = reinterpret_cast<long long*>(base + 5 * tab);     // the U table is unused by this kernel
 #endif
+  // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
+  // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
+  const bool b_on = lane < 58, o_on = lane < 54;
+  const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
+  const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
+  // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
+
+  // QM and QM1 (adjacent tables) through one buffer descriptor
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
+
+
+  // Floating work items of diagonal d, taken from a work queue (LDS counter).  The sweep waves run this after their tower
+  // step; the finalize waves, which are done with diagonal d-1 long before the sweep of d ends, join in: every item owns
+  // its output slots and reads nothing the current step writes, so the result does not depend on who takes it.
+  auto run_items = [&](const int d) {
+    const int ncell = n - d, sh = d >> 1, par = d & 1;
+    const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
+    const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+    // ---- floating items of the diagonal, taken from a work queue (LDS counter): 16-cell multiloop
+    // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
+    // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
+    // not depend on which wave takes it.
+    // K items per 32-cell block: 4 once a single block is left (the operand offsets of the wider stride stay inside the
+    // descriptor only for ld >= 48)
+    const int kssh = (ncell <= 32 && ld >= 48) ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
+    const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
+    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+              nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
+    const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
+    const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
+    const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
+    const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
+    for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+      if (it < nK) {
+        // ---- K: multiloop sum D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j] for 32 cells x 4 interleaved split-point
+        // groups: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
+        // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
+        // When few blocks are left (late diagonals: few cells, long sums) a block's split points are dealt to KS = 2 or 4
+        // items, so that no wave walks the whole sum as one chain of dependent L2 round trips while the others idle;
+        // the rows of such an item are folded inside the wave so that the four slices still suffice.
+        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+        int i = ((it >> kssh) << 5) + 2 * cl + 1;
+        const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+        i = act0 ? i : 1;
+        double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
+        int tt = TURN + 1 + g;
+        // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
+        // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
+        int vA = (tt * ld + i) * 8;
+        int vC = (int)tab * 8 + ((d - tt - 1 - 3 * KG) * ld + i + tt + 1 + 3 * KG) * 8;          // operand of tt + 3 KG
+        for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
+          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
+          const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vC, 2 * cstep);
+          const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vC, cstep);
+          const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vC, 0);
+          vA += 4 * astep; vC -= 4 * cstep;
+          p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
+          p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
+        }
+        for (; tt <= d - TURN - 2; tt += KG) {
+          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
+          p0 += a0.x * c0.x; q0 += a0.y * c0.y;
+          vA += astep; vC -= cstep;
+        }
+        double v0 = p0 + p1, v1 = q0 + q1;
+        int slice = lane >> 4;
+        bool writer = true;
+        if (kssh >= 1) {                       // rows 0+1 and 2+3
+          v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+          slice = (it & (KS - 1)) * (4 >> kssh) + (lane >> 5);
+          writer = (lane & 16) == 0;
+        }
+        if (kssh == 2) {                       // all four rows
+          v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+          writer = lane < 16;
+        }
+        if (writer) {
+          if (act0) sm.partK[par][slice][i + slot0] = v0;
+          if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
+        }
+      } else if (it < nK + nE) {
+        const int q = 2 * (it - nK);
+        const bool two = q + 1 < pcnt;
+        const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
+        const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
+        const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
+        const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
+        const int f00 = sm.info[b_off + i0], f01 = sm.info[o_off + i0];
+        const int f10 = sm.info[b_off + i1], f11 = sm.info[o_off + i1];
+        const double r00 = sm.rbul[f00], r01 = sm.r1n[f01], r10 = sm.rbul[f10], r11 = sm.r1n[f11];
+        const double m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+        const double b_W = sm.eWb[lane], o_W = sm.eWo[lane];
+        double v0 = (b_ok ? w00 * r00 * b_W : 0.0) * ((ij0 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w01 * r01 * o_W : 0.0) * m0;
+        double v1 = (b_ok ? w10 * r10 * b_W : 0.0) * ((ij1 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w11 * r11 * o_W : 0.0) * m1;
+        v0 = wave_total_f64_lane63(v0);
+        v1 = wave_total_f64_lane63(v1);
+        if (lane == WAVE - 1) {
+          sm.accE[par][i0 + slot0] = v0;
+          if (two) sm.accE[par][i1 + slot0] = v1;
+        }
+      } else {
+        const int xi = it - nK - nE;
+        const int ch = xi / 3, grp = xi - 3 * ch;
+        const int q = ch * WAVE + lane;
+        const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+        const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+        double sum;
+        if (grp == 0) {
+          // (0,0) (0,1) (1,0) (1,1): LDS tables
+          double w[4];
+          int f[4];
+#pragma unroll
+          for (int shp = 0; shp < 4; shp++) {
+            const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
+            const int dp = d - 2 - u1 - u2;
+            const int off = (dp & 31) * RS + 1 + u1 + i;
+            w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
+            f[shp] = dp > TURN ? sm.info[off] : 0;
+          }
+          sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
+          sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * sm.xc[as_vector(0)];
+          sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sm.xc[as_vector(2)];
+        } else if (grp == 1) {
+          // (1,2) (2,1) (2,2): tables in global memory (L2)
+          const int dpa = d - 5, dpb = d - 6;
+          const int oa = (dpa & 31) * RS + 2 + i, ob = (dpa & 31) * RS + 3 + i, oc = (dpb & 31) * RS + 3 + i;
+          const double wa = dpa > TURN ? sm.qbi[oa] : 0.0, wb = dpa > TURN ? sm.qbi[ob] : 0.0, wc = dpb > TURN ? sm.qbi[oc] : 0.0;
+          const int fa = dpa > TURN ? sm.info[oa] : 0, fb = dpa > TURN ? sm.info[ob] : 0, fc = dpb > TURN ? sm.info[oc] : 0;
+          const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
+          const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
+          const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
+          sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sm.xc[as_vector(3)] + wc * sm.rinv[fc] * gc * sm.xc[as_vector(4)];
+        } else {
+          // (2,3) (3,2)
+          const int dp = d - 7;
+          const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
+          const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
+          const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
+          sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * sm.xc[as_vector(1)];
+        }
+        if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
+      }
+#ifdef DRNA_STAMPS
+      STAMP(it < nK ? 5 : it < nK + nE ? 1 : 2);
+#endif
+    }
+  };
+
   if (aw < 0) {
     // ================= finalize waves: diagonal d = k-1 at step k
     for (int k = TURN + 1; k <= n; k++) {
@@ -346,6 +494,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       }
       if (!(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
       STAMP(4);
+      if (!(DRNA_SKIP & 128) && k < n) run_items(k);          // help the sweep of diagonal k
       __syncthreads();
       STAMP(3);
 #ifdef DRNA_STAMPS
@@ -360,16 +509,6 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     double GE[PGSLOTS], GO[PGSLOTS];
 #pragma unroll
     for (int q = 0; q < PGSLOTS; q++) { GE[q] = 0.0; GO[q] = 0.0; }
-    // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
-    // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
-    const bool b_on = lane < 58, o_on = lane < 54;
-    const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
-    const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
-    // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
-
-    // QM and QM1 (adjacent tables) through one buffer descriptor
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
-
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
         const int d = k;
@@ -385,135 +524,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
         }
         STAMP(0);
-        const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
-        // ---- floating items of the diagonal, taken from a work queue (LDS counter): 16-cell multiloop
-        // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
-        // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
-        // not depend on which wave takes it.
-        // K items per 32-cell block: 4 once a single block is left (the operand offsets of the wider stride stay inside the
-        // descriptor only for ld >= 48)
-        const int kssh = (ncell <= 32 && ld >= 48) ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
-        const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
-        const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
-                  nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
-        const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
-        const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-        const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
-        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
-        for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
-          if (it < nK) {
-            // ---- K: multiloop sum D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j] for 32 cells x 4 interleaved split-point
-            // groups: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
-            // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
-            // When few blocks are left (late diagonals: few cells, long sums) a block's split points are dealt to KS = 2 or 4
-            // items, so that no wave walks the whole sum as one chain of dependent L2 round trips while the others idle;
-            // the rows of such an item are folded inside the wave so that the four slices still suffice.
-            const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
-            int i = ((it >> kssh) << 5) + 2 * cl + 1;
-            const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
-            i = act0 ? i : 1;
-            double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
-            int tt = TURN + 1 + g;
-            // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
-            // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
-            int vA = (tt * ld + i) * 8;
-            int vC = (int)tab * 8 + ((d - tt - 1 - 3 * KG) * ld + i + tt + 1 + 3 * KG) * 8;          // operand of tt + 3 KG
-            for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
-              const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
-              const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vC, 2 * cstep);
-              const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vC, cstep);
-              const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vC, 0);
-              vA += 4 * astep; vC -= 4 * cstep;
-              p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
-              p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
-            }
-            for (; tt <= d - TURN - 2; tt += KG) {
-              const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
-              p0 += a0.x * c0.x; q0 += a0.y * c0.y;
-              vA += astep; vC -= cstep;
-            }
-            double v0 = p0 + p1, v1 = q0 + q1;
-            int slice = lane >> 4;
-            bool writer = true;
-            if (kssh >= 1) {                       // rows 0+1 and 2+3
-              v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-              slice = (it & (KS - 1)) * (4 >> kssh) + (lane >> 5);
-              writer = (lane & 16) == 0;
-            }
-            if (kssh == 2) {                       // all four rows
-              v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-              writer = lane < 16;
-            }
-            if (writer) {
-              if (act0) sm.partK[par][slice][i + slot0] = v0;
-              if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
-            }
-          } else if (it < nK + nE) {
-            const int q = 2 * (it - nK);
-            const bool two = q + 1 < pcnt;
-            const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
-            const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
-            const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
-            const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
-            const int f00 = sm.info[b_off + i0], f01 = sm.info[o_off + i0];
-            const int f10 = sm.info[b_off + i1], f11 = sm.info[o_off + i1];
-            const double r00 = sm.rbul[f00], r01 = sm.r1n[f01], r10 = sm.rbul[f10], r11 = sm.r1n[f11];
-            const double m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
-            const double b_W = sm.eWb[lane], o_W = sm.eWo[lane];
-            double v0 = (b_ok ? w00 * r00 * b_W : 0.0) * ((ij0 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w01 * r01 * o_W : 0.0) * m0;
-            double v1 = (b_ok ? w10 * r10 * b_W : 0.0) * ((ij1 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w11 * r11 * o_W : 0.0) * m1;
-            v0 = wave_total_f64_lane63(v0);
-            v1 = wave_total_f64_lane63(v1);
-            if (lane == WAVE - 1) {
-              sm.accE[par][i0 + slot0] = v0;
-              if (two) sm.accE[par][i1 + slot0] = v1;
-            }
-          } else {
-            const int xi = it - nK - nE;
-            const int ch = xi / 3, grp = xi - 3 * ch;
-            const int q = ch * WAVE + lane;
-            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-            const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-            double sum;
-            if (grp == 0) {
-              // (0,0) (0,1) (1,0) (1,1): LDS tables
-              double w[4];
-              int f[4];
-#pragma unroll
-              for (int shp = 0; shp < 4; shp++) {
-                const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
-                const int dp = d - 2 - u1 - u2;
-                const int off = (dp & 31) * RS + 1 + u1 + i;
-                w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
-                f[shp] = dp > TURN ? sm.info[off] : 0;
-              }
-              sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
-              sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * sm.xc[as_vector(0)];
-              sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sm.xc[as_vector(2)];
-            } else if (grp == 1) {
-              // (1,2) (2,1) (2,2): tables in global memory (L2)
-              const int dpa = d - 5, dpb = d - 6;
-              const int oa = (dpa & 31) * RS + 2 + i, ob = (dpa & 31) * RS + 3 + i, oc = (dpb & 31) * RS + 3 + i;
-              const double wa = dpa > TURN ? sm.qbi[oa] : 0.0, wb = dpa > TURN ? sm.qbi[ob] : 0.0, wc = dpb > TURN ? sm.qbi[oc] : 0.0;
-              const int fa = dpa > TURN ? sm.info[oa] : 0, fb = dpa > TURN ? sm.info[ob] : 0, fc = dpb > TURN ? sm.info[oc] : 0;
-              const double ga = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1];
-              const double gb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)];
-              const double gc = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1];
-              sum = (wa * sm.rinv[fa] * ga + wb * sm.rinv[fb] * gb) * sm.xc[as_vector(3)] + wc * sm.rinv[fc] * gc * sm.xc[as_vector(4)];
-            } else {
-              // (2,3) (3,2)
-              const int dp = d - 7;
-              const int oa = (dp & 31) * RS + 3 + i, ob = (dp & 31) * RS + 4 + i;
-              const double wa = dp > TURN ? sm.qbi[oa] : 0.0, wb = dp > TURN ? sm.qbi[ob] : 0.0;
-              const int fa = dp > TURN ? sm.info[oa] : 0, fb = dp > TURN ? sm.info[ob] : 0;
-              sum = (wa * sm.r23[fa] + wb * sm.r23[fb]) * sm.mm23[cxv] * sm.xc[as_vector(1)];
-            }
-            if (q < pcnt) sm.accX[par][grp][i + slot0] = sum;
-          }
-#ifdef DRNA_STAMPS
-          STAMP(it < nK ? 5 : it < nK + nE ? 1 : 2);
-#endif
-        }
+        run_items(d);
         STAMP(6);
       }
       __syncthreads();
