@@ -432,6 +432,23 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data}
 
 
+def run_puzzle_set(inputs, rank=0, world=1, driver=None, **kw):
+    """Design every problem of `inputs` (BASELINE config 4), the set sharded over `world` ranks by sum n^3
+    (``replica_exchange.shard_puzzles``): each rank runs its own puzzles with all their replicas on its GPU and the
+    results are gathered once at the end.  Returns {index: dict(name, solved, sequence, mfe_ss, score)} on every rank."""
+    driver = driver or run_design_fast
+    owner = rx.shard_puzzles([len(i.sec_struct) for i in inputs], world)
+    mine = {}
+    for k, inp in enumerate(inputs):
+        if owner[k] != rank:
+            continue
+        res = driver(inp, **kw)
+        b = res["best"]
+        mine[k] = dict(name=inp.name, solved=bool(res["solved"]), sequence=b.sequence, mfe_ss=b.mfe_ss,
+                       score=float(b.scoring_function), rank=rank)
+    return rx.gather_results(mine, world)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="GPU replica-exchange RNA design (flag names follow DesiRNA.py)")
     ap.add_argument("-f", "--filename", required=True, dest="name")

@@ -109,3 +109,30 @@ class ReplicaShards:
             idx = list(range(rk, self.R, self.world))
             full[idx] = out[rk, :len(idx)]
         return full
+
+
+def shard_puzzles(lengths, world):
+    """BASELINE config 4 (a set of independent design problems, e.g. the 100 Eterna100-V1 puzzles): puzzle -> rank by greedy
+    longest-processing-time balancing of sum n^3.  Every rank computes the same assignment; no data-path
+    collective is needed, only the final gather of the results."""
+    order = sorted(range(len(lengths)), key=lambda k: (-int(lengths[k]) ** 3, k))
+    load = [0] * world
+    owner = [0] * len(lengths)
+    for k in order:
+        r = min(range(world), key=lambda x: (load[x], x))
+        owner[k] = r
+        load[r] += int(lengths[k]) ** 3
+    return owner
+
+
+def gather_results(local_results, world):
+    """local_results: {puzzle index: result} of this rank -> the merged dict on every rank (one all_gather_object)."""
+    if world == 1:
+        return dict(local_results)
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, local_results)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return merged

@@ -130,3 +130,56 @@ def test_sharded_design_run_gloo_world2(tmp_path):
     assert sorted(outs[0]["temps"] + outs[1]["temps"]) == sorted(get_rep_temps(6, 10.0, 150.0))
     assert (outs[0]["acc_re"], outs[0]["rej_re"]) == (outs[1]["acc_re"], outs[1]["rej_re"])   # same swap decisions
     assert outs[0]["scored"] == outs[1]["scored"] == 3 + 3 * 10 * 3
+
+
+def test_shard_puzzles_balances_cubes():
+    from desirna_amd.replica_exchange import shard_puzzles
+    lengths = [400, 12, 36, 200, 104, 104, 380, 16, 90, 250]
+    own = shard_puzzles(lengths, 4)
+    load = [sum(l ** 3 for l, o in zip(lengths, own) if o == r) for r in range(4)]
+    assert sorted(set(own)) == [0, 1, 2, 3]
+    assert max(load) <= 400 ** 3 + 36 ** 3 + 16 ** 3 + 12 ** 3          # the longest puzzle sits (almost) alone
+    assert shard_puzzles(lengths, 1) == [0] * len(lengths)
+
+
+def test_puzzle_set_sharded_gloo_world2(tmp_path):
+    """Config 4's multi-rank path on CPU: three small puzzles over two ranks (oracle-backed scorer), results gathered on both."""
+    script = tmp_path / "worker_set.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from types import SimpleNamespace
+        import torch.distributed as dist
+        from desirna_amd import design, params
+        from desirna_amd.energy_scores import parse_scoring_functions
+        from oracle.pyoracle import Oracle
+        from tests.test_design_driver import OracleScorer
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        orc = Oracle(params.load_blob())
+        targets = ["(((((......)))))", "((((....))))", "(((((((....)))))))..."]
+        inputs = [SimpleNamespace(name="p%%d" %% k, sec_struct=t, seq_restr="N" * len(t), seed_seq=None, alt_sec_struct=None,
+                                  alt_sec_structs=None) for k, t in enumerate(targets)]
+        def driver(inp, **kw):
+            sc = OracleScorer(orc, inp.sec_struct, parse_scoring_functions("Ed-Epf:1.0"))
+            return design.run_design(inp, scorer=sc, **kw)
+        res = design.run_puzzle_set(inputs, rank, world, driver=driver, replicas=4, exchange=10, steps=4, seed=5)
+        print(json.dumps({"rank": rank, "res": {str(k): v for k, v in res.items()}}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    port = _free_port()
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    import json
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    assert outs[0]["res"] == outs[1]["res"] and sorted(outs[0]["res"]) == ["0", "1", "2"]
+    ranks = {v["rank"] for v in outs[0]["res"].values()}
+    assert ranks == {0, 1}                                       # both ranks worked
+    for k, v in outs[0]["res"].items():
+        assert len(v["sequence"]) == len(v["mfe_ss"])
