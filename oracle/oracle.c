@@ -1068,3 +1068,394 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
     free(ss); free(ss2);
   }
 }
+
+/* ---------------------------------------------------------------- two strands: co-fold MFE and partition function
+ *
+ * fc.mfe_dimer() / fc.pf_dimer() of reference utils/energy_scores.py:154-158.  seq holds both strands
+ * WITHOUT the '&'; cut = length of the first strand.  Restated from the published co-folding scheme (Bernhart et al. 2006:
+ * concatenate the strands; a loop whose backbone contains the nick is an exterior loop; DuplexInit once for connected
+ * structures; homodimer symmetry correction in the partition function) and PINNED on the two-strand trajectories the
+ * reference committed (538 hetero-dimer + 170 homodimer rows: mfe_dimer strings and pf_dimer free energies).
+ *
+ * Differences from the one-strand recursions:
+ *   - hairpins, multiloops and the unpaired stretches of interior loops must not contain the nick;
+ *   - a pair (i,j) that joins the strands may close the "loop" that contains the nick: E_ExtLoop of the pair seen from
+ *     inside + best exterior decomposition of [i+1..cut] + of [cut+1..j-1] (arrays fcA / fcB; qA3 / qB5 in the PF);
+ *   - dangling neighbours count only inside a strand;
+ *   - MFE = min(f5[n] + DuplexInit, fcA[1] + fcB[n]);  Q = (q5[n] - QA QB) expDuplexInit [/ 2 if both strands are equal]
+ *     + QA QB.
+ */
+#define SAMESTR(a, b) (!((a) <= cut && (b) > cut))
+
+typedef struct {
+  int n, cut, *S, *c, *fML, *f5, *fcA, *fcB;
+  unsigned char *pty;
+  char *up;
+} coctx;
+
+static void co_fill(const orc_params *P, coctx *M, const char *seq, int n, int cut) {
+  const int W = n + 2;
+  size_t W2 = (size_t)W * (size_t)W;
+  M->n = n; M->cut = cut;
+  M->S = encode_seq(seq, n);
+  M->up = (char *)malloc((size_t)n + 1);
+  for (int i = 0; i < n; i++) {
+    char ch = seq[i];
+    ch = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch;
+    M->up[i] = (ch == 'T') ? 'U' : ch;
+  }
+  M->up[n] = 0;
+  M->pty = (unsigned char *)calloc(W2, 1);
+  M->c = (int *)malloc(W2 * sizeof(int));
+  M->fML = (int *)malloc(W2 * sizeof(int));
+  M->f5 = (int *)calloc((size_t)n + 2, sizeof(int));
+  M->fcA = (int *)calloc((size_t)n + 3, sizeof(int));
+  M->fcB = (int *)calloc((size_t)n + 3, sizeof(int));
+  int *S = M->S, *c = M->c, *fML = M->fML, *fcA = M->fcA, *fcB = M->fcB;
+  for (size_t k = 0; k < W2; k++) { c[k] = INF; fML[k] = INF; }
+  for (int i = 1; i <= n; i++)
+    for (int j = i + 1; j <= n; j++)
+      if (j - i > TURN || !SAMESTR(i, j)) M->pty[IDX(i, j)] = (unsigned char)PAIR[S[i]][S[j]];
+  for (int i = n; i >= 1; i--) {
+    if (i == cut) {
+      /* every pair inside the second strand is known: best exterior decomposition of [cut+1..j] */
+      fcB[cut] = 0;
+      for (int j = cut + 1; j <= n; j++) {
+        int f = fcB[j - 1];
+        for (int k = cut + 1; k < j; k++) {
+          int t = M->pty[IDX(k, j)];
+          if (!t || c[IDX(k, j)] >= INF) continue;
+          int en = fcB[k - 1] + c[IDX(k, j)] + E_ExtLoop(P, t, k > cut + 1 ? S[k - 1] : -1, j < n ? S[j + 1] : -1);
+          f = MIN2(f, en);
+        }
+        fcB[j] = f;
+      }
+    }
+    for (int j = i + 1; j <= n; j++) {
+      int t = M->pty[IDX(i, j)];
+      int same = SAMESTR(i, j);
+      int e = INF;
+      if (t) {
+        if (same) e = E_Hairpin(P, j - i - 1, t, S[i + 1], S[j - 1], M->up + i - 1);
+        else {
+          /* the nick lies on the backbone of the loop closed by (i,j) */
+          int en = E_ExtLoop(P, RTYPE[t], SAMESTR(j - 1, j) ? S[j - 1] : -1, SAMESTR(i, i + 1) ? S[i + 1] : -1);
+          e = MIN2(e, en + fcA[i + 1] + fcB[j - 1]);
+        }
+        /* multiloop closed by (i,j): its backbone must not contain the nick (a helix inside may enclose it) */
+        if (SAMESTR(i, i + 1) && SAMESTR(j - 1, j)) {
+          int dec = INF;
+          for (int u = i + 2; u <= j - 2; u++) {
+            if (!SAMESTR(u, u + 1)) continue;
+            int a = fML[IDX(i + 1, u)], b = fML[IDX(u + 1, j - 1)];
+            if (a < INF && b < INF) dec = MIN2(dec, a + b);
+          }
+          if (dec < INF) e = MIN2(e, dec + P->MLclosing + E_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]));
+        }
+        /* interior loops: both unpaired stretches inside one strand */
+        for (int p = i + 1; p <= MIN2(j - 2, i + MAXLOOP + 1); p++) {
+          if (!SAMESTR(i, p)) break;
+          int u1 = p - i - 1;
+          for (int q = j - 1; q > p; q--) {
+            int u2 = j - q - 1;
+            if (u1 + u2 > MAXLOOP) break;
+            if (!SAMESTR(q, j)) break;
+            int t2 = M->pty[IDX(p, q)];
+            if (!t2 || c[IDX(p, q)] >= INF) continue;
+            int en = c[IDX(p, q)] + E_IntLoop(P, u1, u2, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]);
+            e = MIN2(e, en);
+          }
+        }
+      }
+      c[IDX(i, j)] = e;
+      {
+        int f = INF;
+        if (SAMESTR(i, i + 1) && fML[IDX(i + 1, j)] < INF) f = fML[IDX(i + 1, j)] + P->MLbase;
+        if (SAMESTR(j - 1, j) && fML[IDX(i, j - 1)] < INF) f = MIN2(f, fML[IDX(i, j - 1)] + P->MLbase);
+        if (e < INF) f = MIN2(f, e + E_MLstem(P, t, (i > 1 && SAMESTR(i - 1, i)) ? S[i - 1] : -1, (j < n && SAMESTR(j, j + 1)) ? S[j + 1] : -1));
+        for (int u = i + 1; u <= j - 2; u++) {
+          if (!SAMESTR(u, u + 1)) continue;
+          int a = fML[IDX(i, u)], b = fML[IDX(u + 1, j)];
+          if (a < INF && b < INF) f = MIN2(f, a + b);
+        }
+        fML[IDX(i, j)] = f;
+      }
+    }
+    if (i <= cut) {
+      /* best exterior decomposition of [i..cut] */
+      int f = fcA[i + 1];          /* fcA[cut+1] = 0 */
+      for (int k = i + 1; k <= cut; k++) {
+        int t = M->pty[IDX(i, k)];
+        if (!t || c[IDX(i, k)] >= INF) continue;
+        int en = c[IDX(i, k)] + E_ExtLoop(P, t, i > 1 ? S[i - 1] : -1, k < cut ? S[k + 1] : -1) + fcA[k + 1];
+        f = MIN2(f, en);
+      }
+      fcA[i] = f;
+    }
+  }
+  int *f5 = M->f5;
+  f5[0] = 0;
+  for (int j = 1; j <= n; j++) {
+    int f = f5[j - 1];
+    for (int i = j - 1; i >= 1; i--) {
+      int t = M->pty[IDX(i, j)];
+      if (!t || c[IDX(i, j)] >= INF) continue;
+      int en = f5[i - 1] + c[IDX(i, j)] +
+               E_ExtLoop(P, t, (i > 1 && SAMESTR(i - 1, i)) ? S[i - 1] : -1, (j < n && SAMESTR(j, j + 1)) ? S[j + 1] : -1);
+      f = MIN2(f, en);
+    }
+    f5[j] = f;
+  }
+}
+
+static void co_free(coctx *M) {
+  free(M->S); free(M->up); free(M->pty); free(M->c); free(M->fML); free(M->f5); free(M->fcA); free(M->fcB);
+}
+
+int co_bt_order = 1;   /* candidate order of the pair traceback (see co_traceback); settled on the goldens */
+
+/* sectors: 0 = f5[1..j], 1 = fML[i..j], 2 = pair (i,j), 3 = fcA[i..cut], 4 = fcB[cut+1..j] */
+static void co_traceback(const orc_params *P, const coctx *M, char *ss, int dimer) {
+  const int n = M->n, W = n + 2, cut = M->cut;
+  const int *S = M->S, *c = M->c, *fML = M->fML, *f5 = M->f5, *fcA = M->fcA, *fcB = M->fcB;
+  typedef struct { int i, j, ml; } sect;
+  sect *st = (sect *)malloc(sizeof(sect) * (size_t)(4 * n + 8));
+  int sp = 0;
+  memset(ss, '.', (size_t)n);
+  ss[n] = 0;
+  if (dimer) st[sp++] = (sect){1, n, 0};
+  else { st[sp++] = (sect){1, cut, 3}; st[sp++] = (sect){cut + 1, n, 4}; }
+  while (sp > 0) {
+    sect s = st[--sp];
+    int i = s.i, j = s.j;
+    if (s.ml == 0) {
+      int jj = j;
+      while (jj > 0 && f5[jj] == f5[jj - 1]) jj--;
+      if (jj < 2) continue;
+      int found = 0;
+      for (int u = jj - 1; u >= 1; u--) {
+        int t = M->pty[IDX(u, jj)];
+        if (!t || c[IDX(u, jj)] >= INF) continue;
+        int en = c[IDX(u, jj)] + E_ExtLoop(P, t, (u > 1 && SAMESTR(u - 1, u)) ? S[u - 1] : -1,
+                                            (jj < n && SAMESTR(jj, jj + 1)) ? S[jj + 1] : -1);
+        if (f5[jj] == en + f5[u - 1]) { st[sp++] = (sect){1, u - 1, 0}; st[sp++] = (sect){u, jj, 2}; found = 1; break; }
+      }
+      if (!found) { fprintf(stderr, "oracle cofold: f5 traceback failed at %d\n", jj); break; }
+      continue;
+    }
+    if (s.ml == 3) {                     /* fcA[i]: [i..cut] */
+      while (i <= cut && fcA[i] == fcA[i + 1]) i++;
+      if (i > cut) continue;
+      int found = 0;
+      for (int k = i + 1; k <= cut; k++) {
+        int t = M->pty[IDX(i, k)];
+        if (!t || c[IDX(i, k)] >= INF) continue;
+        int en = c[IDX(i, k)] + E_ExtLoop(P, t, i > 1 ? S[i - 1] : -1, k < cut ? S[k + 1] : -1);
+        if (fcA[i] == en + fcA[k + 1]) { st[sp++] = (sect){k + 1, cut, 3}; st[sp++] = (sect){i, k, 2}; found = 1; break; }
+      }
+      if (!found) { fprintf(stderr, "oracle cofold: fcA traceback failed at %d\n", i); break; }
+      continue;
+    }
+    if (s.ml == 4) {                     /* fcB[j]: [cut+1..j] */
+      while (j > cut && fcB[j] == fcB[j - 1]) j--;
+      if (j <= cut) continue;
+      int found = 0;
+      for (int k = j - 1; k > cut; k--) {
+        int t = M->pty[IDX(k, j)];
+        if (!t || c[IDX(k, j)] >= INF) continue;
+        int en = c[IDX(k, j)] + E_ExtLoop(P, t, k > cut + 1 ? S[k - 1] : -1, j < n ? S[j + 1] : -1);
+        if (fcB[j] == en + fcB[k - 1]) { st[sp++] = (sect){cut + 1, k - 1, 4}; st[sp++] = (sect){k, j, 2}; found = 1; break; }
+      }
+      if (!found) { fprintf(stderr, "oracle cofold: fcB traceback failed at %d\n", j); break; }
+      continue;
+    }
+    if (s.ml == 1) {
+      while (j > i && SAMESTR(j - 1, j) && fML[IDX(i, j - 1)] < INF && fML[IDX(i, j)] == fML[IDX(i, j - 1)] + P->MLbase) j--;
+      while (i < j && SAMESTR(i, i + 1) && fML[IDX(i + 1, j)] < INF && fML[IDX(i, j)] == fML[IDX(i + 1, j)] + P->MLbase) i++;
+      int fij = fML[IDX(i, j)];
+      int t = M->pty[IDX(i, j)];
+      if (t && c[IDX(i, j)] < INF &&
+          fij == c[IDX(i, j)] + E_MLstem(P, t, (i > 1 && SAMESTR(i - 1, i)) ? S[i - 1] : -1, (j < n && SAMESTR(j, j + 1)) ? S[j + 1] : -1)) {
+        st[sp++] = (sect){i, j, 2};
+        continue;
+      }
+      int found = 0;
+      for (int u = i + 1; u <= j - 2; u++)
+        if (SAMESTR(u, u + 1) && fML[IDX(i, u)] < INF && fML[IDX(u + 1, j)] < INF && fij == fML[IDX(i, u)] + fML[IDX(u + 1, j)]) {
+          st[sp++] = (sect){i, u, 1}; st[sp++] = (sect){u + 1, j, 1}; found = 1; break;
+        }
+      if (!found) { fprintf(stderr, "oracle cofold: fML traceback failed at %d,%d\n", i, j); break; }
+      continue;
+    }
+    for (;;) {
+      ss[i - 1] = '(';
+      ss[j - 1] = ')';
+      int t = M->pty[IDX(i, j)];
+      int cij = c[IDX(i, j)];
+      if (SAMESTR(i, j) && cij == E_Hairpin(P, j - i - 1, t, S[i + 1], S[j - 1], M->up + i - 1)) break;
+      int found = 0;
+      for (int pass = 0; pass < 3 && !found; pass++) {
+        const int what = co_bt_order == 0 ? (pass == 0 ? 'N' : pass == 1 ? 'I' : 'M')
+                       : co_bt_order == 1 ? (pass == 0 ? 'I' : pass == 1 ? 'N' : 'M')
+                                          : (pass == 0 ? 'I' : pass == 1 ? 'M' : 'N');
+        if (what == 'N') {
+          if (SAMESTR(i, j)) continue;
+          int en = E_ExtLoop(P, RTYPE[t], SAMESTR(j - 1, j) ? S[j - 1] : -1, SAMESTR(i, i + 1) ? S[i + 1] : -1);
+          if (cij == en + fcA[i + 1] + fcB[j - 1]) {
+            st[sp++] = (sect){i + 1, cut, 3};
+            st[sp++] = (sect){cut + 1, j - 1, 4};
+            found = 2;
+          }
+        } else if (what == 'I') {
+          for (int p = i + 1; p <= MIN2(j - 2, i + MAXLOOP + 1) && !found; p++) {
+            if (!SAMESTR(i, p)) break;
+            for (int q = j - 1; q > p; q--) {
+              if (p - i - 1 + j - q - 1 > MAXLOOP) break;
+              if (!SAMESTR(q, j)) break;
+              int t2 = M->pty[IDX(p, q)];
+              if (!t2 || c[IDX(p, q)] >= INF) continue;
+              int en = E_IntLoop(P, p - i - 1, j - q - 1, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]);
+              if (cij == en + c[IDX(p, q)]) { i = p; j = q; found = 1; break; }
+            }
+          }
+        } else {
+          if (!(SAMESTR(i, i + 1) && SAMESTR(j - 1, j))) continue;
+          int e = cij - P->MLclosing - E_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]);
+          for (int u = i + 2; u <= j - 2; u++)
+            if (SAMESTR(u, u + 1) && fML[IDX(i + 1, u)] < INF && fML[IDX(u + 1, j - 1)] < INF &&
+                e == fML[IDX(i + 1, u)] + fML[IDX(u + 1, j - 1)]) {
+              st[sp++] = (sect){i + 1, u, 1}; st[sp++] = (sect){u + 1, j - 1, 1}; found = 2; break;
+            }
+        }
+      }
+      if (found == 1) continue;
+      if (!found) fprintf(stderr, "oracle cofold: pair traceback failed at %d,%d\n", i, j);
+      break;
+    }
+  }
+  free(st);
+}
+
+int orc_cofold_mfe(const orc_params *P, const char *seq, int n, int cut, char *ss) {
+  coctx M;
+  co_fill(P, &M, seq, n, cut);
+  const int e_dimer = M.f5[n] + P->DuplexInit, e_mono = M.fcA[1] + M.fcB[n];
+  const int dimer = e_dimer < e_mono;
+  if (ss) co_traceback(P, &M, ss, dimer);
+  co_free(&M);
+  return dimer ? e_dimer : e_mono;
+}
+
+/* out[0] = FA, out[1] = FB, out[2] = FcAB (true hybrids, DuplexInit and symmetry applied), out[3] = FAB */
+void orc_cofold_pf(const orc_params *P, const char *seq, int n, int cut, double out[4]) {
+  const int W = n + 2;
+  size_t W2 = (size_t)W * (size_t)W;
+  int *S = encode_seq(seq, n);
+  char *up = (char *)malloc((size_t)n + 1);
+  for (int i = 0; i < n; i++) {
+    char ch = seq[i];
+    ch = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch;
+    up[i] = (ch == 'T') ? 'U' : ch;
+  }
+  up[n] = 0;
+  double *qb = (double *)calloc(W2, sizeof(double)), *qm = (double *)calloc(W2, sizeof(double)),
+         *qm1 = (double *)calloc(W2, sizeof(double));
+  double *q5 = (double *)calloc((size_t)n + 2, sizeof(double)), *qA3 = (double *)calloc((size_t)n + 3, sizeof(double)),
+         *qB5 = (double *)calloc((size_t)n + 3, sizeof(double));
+  double *scale = (double *)malloc(sizeof(double) * (size_t)(n + 3)), *eMLb = (double *)malloc(sizeof(double) * (size_t)(n + 3));
+  scale[0] = 1.0; eMLb[0] = 1.0;
+  for (int k = 1; k <= n + 2; k++) { scale[k] = scale[k - 1] / P->pf_scale; eMLb[k] = eMLb[k - 1] * P->eMLbase / P->pf_scale; }
+#define PT(i, j) (((j) - (i) > TURN || !SAMESTR(i, j)) ? PAIR[S[i]][S[j]] : 0)
+  for (int i = n; i >= 1; i--) {
+    if (i == cut) {
+      qB5[cut] = 1.0;
+      for (int j = cut + 1; j <= n; j++) {
+        double q = qB5[j - 1] * scale[1];
+        for (int k = cut + 1; k < j; k++) {
+          int t = PT(k, j);
+          if (!t) continue;
+          q += qB5[k - 1] * qb[IDX(k, j)] * X_ExtLoop(P, t, k > cut + 1 ? S[k - 1] : -1, j < n ? S[j + 1] : -1);
+        }
+        qB5[j] = q;
+      }
+    }
+    for (int j = i + 1; j <= n; j++) {
+      int t = PT(i, j);
+      int same = SAMESTR(i, j);
+      double b = 0.0;
+      if (t) {
+        if (same) {
+          int u = j - i - 1;
+          b = X_Hairpin(P, u, t, S[i + 1], S[j - 1], up + i - 1) * scale[u + 2];
+        } else {
+          b += qA3[i + 1] * qB5[j - 1] * scale[2] *
+               X_ExtLoop(P, RTYPE[t], SAMESTR(j - 1, j) ? S[j - 1] : -1, SAMESTR(i, i + 1) ? S[i + 1] : -1);
+        }
+        if (SAMESTR(i, i + 1) && SAMESTR(j - 1, j)) {
+          /* multiloop: the backbone stays inside a strand, a helix inside may enclose the nick */
+          double tmp = 0.0;
+          for (int k = i + 3; k <= j - 2; k++)
+            if (SAMESTR(k - 1, k)) tmp += qm[IDX(i + 1, k - 1)] * qm1[IDX(k, j - 1)];
+          b += tmp * P->eMLclosing * X_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]) * scale[2];
+        }
+        for (int p = i + 1; p <= MIN2(j - 2, i + MAXLOOP + 1); p++) {
+          if (!SAMESTR(i, p)) break;
+          int u1 = p - i - 1;
+          for (int q = j - 1; q > p; q--) {
+            int u2 = j - q - 1;
+            if (u1 + u2 > MAXLOOP) break;
+            if (!SAMESTR(q, j)) break;
+            int t2 = PT(p, q);
+            if (!t2) continue;
+            b += qb[IDX(p, q)] * X_IntLoop(P, u1, u2, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]) * scale[u1 + u2 + 2];
+          }
+        }
+      }
+      qb[IDX(i, j)] = b;
+      {
+        double m1 = SAMESTR(j - 1, j) ? qm1[IDX(i, j - 1)] * eMLb[1] : 0.0;
+        if (t) m1 += b * X_MLstem(P, t, (i > 1 && SAMESTR(i - 1, i)) ? S[i - 1] : -1, (j < n && SAMESTR(j, j + 1)) ? S[j + 1] : -1);
+        qm1[IDX(i, j)] = m1;
+        double m = m1;
+        for (int k = i + 1; k <= j - 1; k++) {
+          double left = SAMESTR(k - 1, k) ? qm[IDX(i, k - 1)] : 0.0;     /* qm[i,k-1] then a stem at k: k-1, k adjacent */
+          if (SAMESTR(i, k)) left += eMLb[k - i];                        /* i..k-1 unpaired, stem at k */
+          m += left * qm1[IDX(k, j)];
+        }
+        qm[IDX(i, j)] = m;
+      }
+    }
+    if (i <= cut) {
+      double q = (i + 1 <= cut ? qA3[i + 1] : 1.0) * scale[1];
+      for (int k = i + 1; k <= cut; k++) {
+        int t = PT(i, k);
+        if (!t) continue;
+        q += qb[IDX(i, k)] * X_ExtLoop(P, t, i > 1 ? S[i - 1] : -1, k < cut ? S[k + 1] : -1) * (k + 1 <= cut ? qA3[k + 1] : 1.0);
+      }
+      qA3[i] = q;
+    }
+    if (i == cut + 1) qA3[cut + 1] = 1.0;
+  }
+  q5[0] = 1.0;
+  for (int j = 1; j <= n; j++) {
+    double q = q5[j - 1] * scale[1];
+    for (int i = j - 1; i >= 1; i--) {
+      int t = PT(i, j);
+      if (!t) continue;
+      q += q5[i - 1] * qb[IDX(i, j)] *
+           X_ExtLoop(P, t, (i > 1 && SAMESTR(i - 1, i)) ? S[i - 1] : -1, (j < n && SAMESTR(j, j + 1)) ? S[j + 1] : -1);
+    }
+    q5[j] = q;
+  }
+#undef PT
+  const double kT = P->kT / 1000.0, lsc = log(P->pf_scale);
+  const double QA = qA3[1], QB = qB5[n], Q0 = q5[n];
+  double QAB = (Q0 - QA * QB) * exp(-(double)P->DuplexInit * 10.0 / P->kT);
+  if (n == 2 * cut && strncmp(up, up + cut, (size_t)cut) == 0) QAB /= 2.0;   /* rotational symmetry of a homodimer */
+  const double Qtot = QA * QB + QAB;
+  out[0] = -kT * (log(QA) + cut * lsc);
+  out[1] = -kT * (log(QB) + (n - cut) * lsc);
+  out[2] = QAB > 1e-17 ? -kT * (log(QAB) + n * lsc) : 999.0;
+  out[3] = -kT * (log(Qtot) + n * lsc);
+  free(S); free(up); free(qb); free(qm); free(qm1); free(q5); free(qA3); free(qB5); free(scale); free(eMLb);
+}

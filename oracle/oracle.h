@@ -67,6 +67,11 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
                      const char *targets, unsigned flags, int threads, double *Epf,
                      int32_t *Emfe, char *mfe_ss, int32_t *Ed);
 
+/* two strands (seq WITHOUT '&', cut = length of the first strand): fc.mfe_dimer() -> structure (n chars + NUL, no '&')
+ * and energy (dcal/mol); fc.pf_dimer() -> out[0..3] = FA, FB, FcAB, FAB (kcal/mol; the reference uses [-1] = FAB) */
+int orc_cofold_mfe(const orc_params *P, const char *seq, int n, int cut, char *ss);
+void orc_cofold_pf(const orc_params *P, const char *seq, int n, int cut, double out[4]);
+
 /* table dumps for kernel-level parity tests: c / fML as (n+2)*(n+2) row-major int32 */
 int orc_mfe_tables(const orc_params *P, const char *seq, int n, const unsigned char *nopair,
                    int32_t *c, int32_t *fML, int32_t *f5);

@@ -103,6 +103,27 @@ class Oracle:
                                          bpp.ctypes.data if want_bpp else None)
         return (ed, bpp) if want_bpp else ed
 
+    def cofold_mfe(self, seq_with_amp):
+        """fc.mfe_dimer(): (structure with '&' re-inserted, energy in dcal/mol)"""
+        a, b = seq_with_amp.split("&")
+        s = a + b
+        buf = C.create_string_buffer(len(s) + 1)
+        self._L.orc_cofold_mfe.restype = C.c_int
+        self._L.orc_cofold_mfe.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        e = self._L.orc_cofold_mfe(self._P, s.encode(), len(s), len(a), buf)
+        ss = buf.value.decode()
+        return ss[:len(a)] + "&" + ss[len(a):], e
+
+    def cofold_pf(self, seq_with_amp):
+        """fc.pf_dimer()[1:]: (FA, FB, FcAB, FAB) in kcal/mol"""
+        a, b = seq_with_amp.split("&")
+        s = a + b
+        out = (C.c_double * 4)()
+        self._L.orc_cofold_pf.restype = None
+        self._L.orc_cofold_pf.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        self._L.orc_cofold_pf(self._P, s.encode(), len(s), len(a), out)
+        return tuple(out)
+
     def simscore(self, ref, query):
         out = (C.c_double * 3)()
         conf = (C.c_int * 4)()

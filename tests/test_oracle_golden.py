@@ -153,3 +153,32 @@ def test_pf_and_bpp_against_enumeration(oracle):
         assert 0.0 <= ed <= 1.0
         p = bpp + bpp.T
         assert (p.sum(axis=1) <= 1 + 1e-9).all()
+
+
+# ---- two strands: co-fold MFE and partition function, pinned on the reference's two-strand trajectories
+
+def test_cofold_goldens(oracle, traj_golden):
+    """fc.mfe_dimer() strings and fc.pf_dimer()[-1] free energies of every sequence of the hetero-dimer (538) and homodimer
+    (170, rotational-symmetry correction) example runs; E(structure) of the two-strand evaluation agrees with the DP."""
+    rows = [r for r in traj_golden if "&" in r["sequence"]]
+    assert len(rows) == 708
+    worst = 0.0
+    for r in rows:
+        ss, e = oracle.cofold_mfe(r["sequence"])
+        assert ss == r["mfe_ss"], r["sequence"]
+        a, b = r["sequence"].split("&")
+        assert e == oracle.eval_structure(a + b, ss.replace("&", ""), cut=len(a)), r["sequence"]
+        fab = oracle.cofold_pf(r["sequence"])[3]
+        worst = max(worst, abs(fab - float(r["Epf"])))
+    assert worst < 2e-6          # goldens are float32
+
+
+def test_cofold_reduces_to_monomers_when_strands_cannot_interact(oracle):
+    """Two strands with no possible inter-strand pair: the dimer ensemble is the product of the monomer ensembles."""
+    a, b = "GGGAAACCC", "GGGAAAACCC"          # G-C only inside each strand... but G/C across strands can pair: use poly-A spacer
+    a, b = "AAAAAAAAA", "AAAAAAAAAA"
+    fa, fb, fcab, fab = oracle.cofold_pf(a + "&" + b)
+    assert abs(fa - oracle.pf(a)) < 1e-9 and abs(fb - oracle.pf(b)) < 1e-9
+    assert abs(fab - (fa + fb)) < 1e-9 and fcab == 999.0
+    ss, e = oracle.cofold_mfe(a + "&" + b)
+    assert ss == "." * len(a) + "&" + "." * len(b) and e == 0
