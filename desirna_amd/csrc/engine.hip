@@ -17,6 +17,7 @@
 #include "../../include/desirna_amd.h"
 #include "eval_structure.hpp"
 #include "fold_mfe.hpp"
+#include "fold_cofold.hpp"
 #include "fold_mfe_lds.hpp"
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
@@ -65,6 +66,7 @@ struct drna_engine {
   short* d_rpt = nullptr;
   int* d_rpt_off = nullptr;
   std::vector<int> rt_len;
+  double* d_F4 = nullptr;   // co-fold free energies (FA, FB, FcAB, FAB per pair)
   std::string err;
 };
 
@@ -153,7 +155,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   if (!e) return;
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
-                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off};
+                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -608,6 +610,82 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, total, hipMemcpyDeviceToHost));
   }
   if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
+
+// ---------------------------------------------------------------- two strands (co-fold)
+
+template <int NT>
+static void launch_cofold(const CoArgs& a, int R, bool mfe, bool pf, hipStream_t sm, hipStream_t sp) {
+  if (pf) hipLaunchKernelGGL(cofold_pf_kernel<NT>, dim3(R), dim3(NT), 0, sp, a);
+  if (mfe) hipLaunchKernelGGL(cofold_mfe_kernel<NT>, dim3(R), dim3(NT), 0, sm, a);
+}
+
+extern "C" int drna_cofold_batch(drna_engine* e, int R, int L, int cut, const char* seqs, uint32_t flags, double* F4,
+                                 int32_t* Emfe, char* mfe_ss, int32_t* Ed) {
+  if (!e) return DRNA_ERR_ARG;
+  const bool want_pf = flags & DRNA_NEED_PF, want_mfe = flags & DRNA_NEED_MFE, want_ev = flags & DRNA_NEED_EVAL;
+  if (R < 1 || R > e->max_R || L < 2 || L > e->max_L || cut < 1 || cut >= L || !seqs || (want_pf && !F4) ||
+      (want_mfe && (!Emfe || !mfe_ss)) || (want_ev && !Ed) || (flags & DRNA_NEED_PK)) {
+    e->err = "drna_cofold_batch: bad argument (1 <= cut < L <= max_L, R <= max_R; output pointers for every requested flag; no NEED_PK)";
+    return DRNA_ERR_ARG;
+  }
+  if (want_ev && (e->n_targets < 1 || e->L_targets != L)) {
+    e->err = "drna_cofold_batch: DRNA_NEED_EVAL needs drna_set_targets() with the same L ('&' removed)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_F4) HIP_TRY(hipMalloc((void**)&e->d_F4, (size_t)4 * e->max_R * sizeof(double)));
+  HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
+  const int ld = L + 2;
+  for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
+  CoArgs a;
+  a.T = e->d_mfeT; a.F = e->d_pfT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.hp_w = e->d_hp_w;
+  a.scale = e->d_scale; a.eMLb = e->d_eMLb; a.seqs = e->d_seqs; a.L = L; a.cut = cut; a.ld = ld;
+  a.DuplexInit = e->H.DuplexInit;
+  a.eDuplexInit = std::exp(-(double)e->H.DuplexInit * 10.0 / e->H.pf.kT);
+  a.wsm = e->d_ws_mfe; a.wsm_stride = (long long)mfe_ws_stride(ld);
+  a.wsp = e->d_ws_pf; a.wsp_stride = (long long)pf_ws_stride(ld);
+  a.Emfe = e->d_Emfe; a.ss = e->d_ss; a.F4 = e->d_F4; a.status = e->d_status; a.status_pf = e->d_status + e->max_R;
+  HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
+  HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+  if (e->nt == 256) launch_cofold<256>(a, R, want_mfe, want_pf, e->s_mfe, e->s_pf);
+  else if (e->nt == 512) launch_cofold<512>(a, R, want_mfe, want_pf, e->s_mfe, e->s_pf);
+  else launch_cofold<1024>(a, R, want_mfe, want_pf, e->s_mfe, e->s_pf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
+  HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+  if (want_ev) {
+    EvalArgs v;
+    v.T = e->d_mfeT; v.hp_len = e->d_hp_len; v.bulge_len = e->d_bulge_len; v.int_len = e->d_int_len;
+    v.seqs = e->d_seqs; v.pt = e->d_pt; v.L = L; v.n_targets = e->n_targets; v.Ed = e->d_Ed;
+    v.cut = cut; v.DuplexInit = e->H.DuplexInit;
+    hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, e->s_eval, v);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(e->s_pf));
+  HIP_TRY(hipStreamSynchronize(e->s_mfe));
+  HIP_TRY(hipStreamSynchronize(e->s_eval));
+  HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
+  HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
+  e->timing[2] = 0.f; e->timing[3] = e->timing[0] > e->timing[1] ? e->timing[0] : e->timing[1];
+  for (int r = 0; r < R; r++) {
+    const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
+    const int st = sm != ST_OK ? sm : sp;
+    if (st == ST_OK) continue;
+    char buf[160];
+    snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
+                              : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"
+                                                  : "sequence %d: traceback could not reproduce a table value", r);
+    e->err = buf;
+    return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;
+  }
+  if (want_pf) HIP_TRY(hipMemcpy(F4, e->d_F4, (size_t)4 * R * sizeof(double), hipMemcpyDeviceToHost));
+  if (want_mfe) {
+    HIP_TRY(hipMemcpy(Emfe, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, (size_t)R * L, hipMemcpyDeviceToHost));
+  }
+  if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * e->n_targets * sizeof(int32_t), hipMemcpyDeviceToHost));
   return DRNA_OK;
 }
 

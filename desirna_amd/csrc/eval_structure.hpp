@@ -27,6 +27,10 @@ struct EvalArgs {
   Ragged rg;
   const int* target_of = nullptr;
   const int* pt_off = nullptr;
+  // two strands (concatenated, no '&'): cut = length of the first one (0 = one strand); a loop whose backbone contains
+  // the nick is scored like an exterior loop, DuplexInit once if any pair joins the strands
+  int cut = 0;
+  int DuplexInit = 0;
 };
 
 struct EvalSmem {
@@ -41,9 +45,39 @@ __device__ __forceinline__ int eval_ptype(const EvalSmem& sm, int i, int j) {
 
 __device__ __forceinline__ int eval_mm(const int* tab, int t, int a, int b) { return tab[t * 16 + a * 4 + b]; }
 
+// E_ExtLoop with explicit neighbour flags
+__device__ __forceinline__ int eval_ext(const MfeTables& T, int t, bool h5, int s5, bool h3, int s3) {
+  int x;
+  if (h5 && h3) x = eval_mm(T.mmExt, t, s5, s3);
+  else if (h5) x = T.d5[t * 4 + s5];
+  else if (h3) x = T.d3[t * 4 + s3];
+  else x = 0;
+  return x + (t > 2 ? T.TermAU : 0);
+}
+
 __device__ inline int eval_loop(const EvalSmem& sm, const EvalArgs& A, int i, int j) {
   const MfeTables& T = *A.T;
   const int t = eval_ptype(sm, i, j);
+  const int cut = A.cut;
+  if (cut > 0 && i <= cut && cut < j) {
+    // does the nick lie on THIS loop's backbone (not inside one of its stems)?
+    bool nick = true;
+    for (int p = i + 1; p < j;) {
+      const int q = sm.pt[p];
+      if (q > p) { if (p <= cut && cut < q) { nick = false; break; } p = q + 1; } else p++;
+    }
+    if (nick) {
+      int e = eval_ext(T, eval_ptype(sm, j, i), j - 1 > cut || j <= cut, sm.S[j - 1], !(i <= cut && i + 1 > cut), sm.S[i + 1]);
+      for (int p = i + 1; p < j;) {
+        const int q = sm.pt[p];
+        if (q > p) {
+          e += eval_ext(T, eval_ptype(sm, p, q), !(p - 1 <= cut && p > cut), sm.S[p - 1], !(q <= cut && q + 1 > cut), sm.S[q + 1]);
+          p = q + 1;
+        } else p++;
+      }
+      return e;
+    }
+  }
   // walk the backbone: count stems and unpaired bases, remember the first stem
   int nst = 0, unp = 0, p1 = 0, q1 = 0;
   int e_stems = 0;
@@ -143,12 +177,10 @@ __global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
       const int j = sm.pt[i];
       if (j > i) {
         const int t = eval_ptype(sm, i, j);
-        int x;
-        if (i > 1 && j < n) x = eval_mm(T.mmExt, t, sm.S[i - 1], sm.S[j + 1]);
-        else if (i > 1) x = T.d5[t * 4 + sm.S[i - 1]];
-        else if (j < n) x = T.d3[t * 4 + sm.S[j + 1]];
-        else x = 0;
-        e += x + (t > 2 ? T.TermAU : 0);
+        const int cut = A.cut;
+        e += eval_ext(T, t, i > 1 && !(cut > 0 && i - 1 <= cut && i > cut), sm.S[i - 1],
+                      j < n && !(cut > 0 && j <= cut && j + 1 > cut), sm.S[j + 1]);
+        if (cut > 0 && i <= cut && j > cut) e += A.DuplexInit;       // an exterior stem that joins the strands: at most one
         i = j + 1;
       } else i++;
     }

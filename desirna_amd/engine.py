@@ -24,7 +24,7 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch")
 
 
 class EngineError(RuntimeError):
@@ -68,6 +68,8 @@ def load_library(path=None):
     L.drna_set_targets_ragged.argtypes = [vp, ci, vp, C.c_char_p]
     L.drna_score_ragged.restype = ci
     L.drna_score_ragged.argtypes = [vp, ci, vp, C.c_char_p, vp, u32, vp, vp, vp, vp]
+    L.drna_cofold_batch.restype = ci
+    L.drna_cofold_batch.argtypes = [vp, ci, ci, ci, C.c_char_p, u32, vp, vp, vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -184,6 +186,34 @@ class Engine:
             offs = np.concatenate(([0], np.cumsum(lens)))
             out_ss = [b[offs[k]:offs[k + 1]] for k in range(R)]
         return {"Epf": Epf, "Emfe": Emfe, "mfe_ss": out_ss, "Ed": Ed}
+
+    def cofold_batch(self, seqs, flags=NEED_PF | NEED_MFE | NEED_EVAL):
+        """Two-strand scoring: seqs are 'AAAA&BBBB' strings with the same strand lengths.  Returns dict(FA, FB, FcAB, FAB
+        (kcal/mol; the reference's Epf is FAB), Emfe (dcal/mol), mfe_ss (with the '&' re-inserted), Ed (vs. set_targets))."""
+        a0, b0 = seqs[0].split("&")
+        cut, L = len(a0), len(a0) + len(b0)
+        flat = []
+        for s in seqs:
+            a, b = s.split("&")
+            if len(a) != cut or len(a) + len(b) != L:
+                raise ValueError("all pairs of a batch must have the same strand lengths")
+            flat.append(a + b)
+        R = len(flat)
+        if not (flags & NEED_EVAL and self.n_targets):
+            flags &= ~NEED_EVAL
+        F4 = np.zeros((R, 4), dtype=np.float64) if flags & NEED_PF else None
+        Emfe = np.zeros(R, dtype=np.int32) if flags & NEED_MFE else None
+        ss = np.zeros((R, L), dtype=np.uint8) if flags & NEED_MFE else None
+        Ed = np.zeros((R, max(1, self.n_targets)), dtype=np.int32) if flags & NEED_EVAL else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.drna_cofold_batch(self._h, R, L, cut, "".join(flat).encode("ascii"), flags, ptr(F4), ptr(Emfe),
+                                              ptr(ss), ptr(Ed)))
+        out = {"Emfe": Emfe, "Ed": Ed, "mfe_ss": None, "FA": None, "FB": None, "FcAB": None, "FAB": None}
+        if ss is not None:
+            out["mfe_ss"] = [bytes(r[:cut]).decode() + "&" + bytes(r[cut:]).decode() for r in ss]
+        if F4 is not None:
+            out.update(FA=F4[:, 0], FB=F4[:, 1], FcAB=F4[:, 2], FAB=F4[:, 3])
+        return out
 
     def ensemble_defect(self, seqs, want_bpp=False):
         """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
@@ -302,5 +332,5 @@ class HostKernels:
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
             raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch")
         return acc.astype(bool), bet.astype(bool)

@@ -111,6 +111,17 @@ int drna_score_ragged(drna_engine *e, int R, const int32_t *lens, const char *se
                       uint32_t flags, double *Epf, int32_t *Emfe, char *mfe_ss, int32_t *Ed);
 
 /*
+ * Two interacting strands (reference oligo_state homodimer / heterodimer, utils/energy_scores.py:154-158): R sequence
+ * pairs of total length L, both strands concatenated WITHOUT the '&', the first strand `cut` nucleotides long.
+ * Replaces fc.mfe_dimer() (structure + energy; the caller re-inserts the '&' at `cut`), fc.pf_dimer() (F4 = FA, FB, FcAB,
+ * FAB in kcal/mol per pair; the reference's Epf is FAB = pf_dimer()[-1]; homodimer symmetry correction included) and the
+ * two-strand fc.eval_structure (Ed against the structures of drna_set_targets, '&' removed, same cut).
+ *   F4 R*4 doubles (NEED_PF), Emfe R int32 + mfe_ss R*L chars (NEED_MFE), Ed R*n_targets int32 (NEED_EVAL)
+ */
+int drna_cofold_batch(drna_engine *e, int R, int L, int cut, const char *seqs, uint32_t flags, double *F4,
+                      int32_t *Emfe, char *mfe_ss, int32_t *Ed);
+
+/*
  * Ensemble defect of R sequences against targets[0] (needs drna_set_targets with the same L): inside fill,
  * outside recursion, base-pair probabilities, then (1/L) * [ sum_{i unpaired in target} sum_j P(i,j)
  * + sum_{i paired with m in target} (1 - P(i,m)) ], '(' ')' pairs only.

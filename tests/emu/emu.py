@@ -22,6 +22,7 @@ def build():
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
+    L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
     L.emu_edef.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, ci, vp, vp, vp]
     return L
 
@@ -109,3 +110,31 @@ class Emu:
         assert rc == 0
         b = ss.tobytes().decode()
         return E, [b[offs[k]:offs[k] + lens[k]] for k in range(R)], Ep, st
+
+    def cofold(self, seqs, target=None, nt=128):
+        """two strands ('AAA&BBB'): co-fold MFE + PF kernels, and E(target) by the eval kernel with the nick"""
+        a0, b0 = seqs[0].split("&")
+        cut, L, R = len(a0), len(a0) + len(b0), len(seqs)
+        flat = "".join(s.replace("&", "") for s in seqs)
+        E = np.zeros(R, dtype=np.int32)
+        ss = np.zeros((R, L), dtype=np.uint8)
+        F4 = np.zeros((R, 4))
+        st = np.zeros(2 * R, dtype=np.int32)
+        pt = Ed = None
+        if target is not None:
+            pt = np.zeros(L + 2, dtype=np.int16)
+            stk = []
+            for i, ch in enumerate(target.replace("&", ""), 1):
+                if ch == "(":
+                    stk.append(i)
+                elif ch == ")":
+                    o = stk.pop()
+                    pt[o] = i
+                    pt[i] = o
+            Ed = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_cofold(self.blob.ctypes.data, self.blob.size, R, L, cut, flat.encode(), nt, E.ctypes.data, ss.ctypes.data,
+                               F4.ctypes.data, st.ctypes.data, pt.ctypes.data if pt is not None else None,
+                               Ed.ctypes.data if Ed is not None else None)
+        assert rc == 0
+        strs = [bytes(r[:cut]).decode() + "&" + bytes(r[cut:]).decode() for r in ss]
+        return E, strs, F4, st, Ed

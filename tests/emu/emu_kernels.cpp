@@ -12,6 +12,7 @@ emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
 #include "../../desirna_amd/csrc/fold_outside.hpp"
+#include "../../desirna_amd/csrc/fold_cofold.hpp"
 
 using namespace drna;
 
@@ -163,6 +164,36 @@ int emu_ragged(const int32_t* blob, int n_int32, int R, int max_L, const int32_t
       emu_launch(r, 128, [&]() { mfe_kernel<128>(a); });
       emu_launch(r, 128, [&]() { pf_kernel<128>(b); });
     }
+  }
+  delete c;
+  return 0;
+}
+
+// two strands: co-fold MFE + PF kernels (and the eval kernel with the nick) for R pairs of total length L
+int emu_cofold(const int32_t* blob, int n_int32, int R, int L, int cut, const char* seqs, int nt, int32_t* Emfe, char* ss,
+               double* F4, int32_t* status, const short* pt, int32_t* Ed) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  std::vector<int32_t> wsm((size_t)5 * ld * ld, 0);
+  const size_t pstride = (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8;
+  std::vector<double> wsp(pstride, 0.0);
+  for (int r = 0; r < R; r++) {
+    CoArgs a;
+    a.T = &c->H.mfe; a.F = &c->H.pf; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data(); a.hp_w = c->H.hp_w.data();
+    a.scale = c->H.scale.data(); a.eMLb = c->H.eMLb.data(); a.seqs = seqs; a.L = L; a.cut = cut; a.ld = ld;
+    a.DuplexInit = c->H.DuplexInit; a.eDuplexInit = std::exp(-(double)c->H.DuplexInit * 10.0 / c->H.pf.kT);
+    a.wsm = wsm.data() - (size_t)r * 5 * ld * ld; a.wsm_stride = (long long)5 * ld * ld;
+    a.wsp = wsp.data() - (size_t)r * pstride; a.wsp_stride = (long long)pstride;
+    a.Emfe = Emfe; a.ss = ss; a.F4 = F4; a.status = status; a.status_pf = status + R;
+    if (nt == 64) { emu_launch(r, 64, [&]() { cofold_mfe_kernel<64>(a); }); emu_launch(r, 64, [&]() { cofold_pf_kernel<64>(a); }); }
+    else { emu_launch(r, 128, [&]() { cofold_mfe_kernel<128>(a); }); emu_launch(r, 128, [&]() { cofold_pf_kernel<128>(a); }); }
+  }
+  if (pt && Ed) {
+    EvalArgs v;
+    v.T = &c->H.mfe; v.hp_len = c->H.hp_len.data(); v.bulge_len = c->H.bulge_len.data(); v.int_len = c->H.int_len.data();
+    v.seqs = seqs; v.pt = pt; v.L = L; v.n_targets = 1; v.Ed = Ed; v.cut = cut; v.DuplexInit = c->H.DuplexInit;
+    for (int b = 0; b < R; b++) emu_launch(b, 64, [&]() { eval_kernel(v); });
   }
   delete c;
   return 0;

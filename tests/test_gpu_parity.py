@@ -298,3 +298,39 @@ def test_ragged_edges_and_errors(eng400, oracle):
     with pytest.raises(E.EngineError) as ei:
         eng400.score_ragged(["GGGANACCC"], None)
     assert ei.value.code == -4
+
+
+# ---- two strands: fc.mfe_dimer / fc.pf_dimer / two-strand eval_structure on the GPU
+
+def test_cofold_golden_trajectories(eng400, traj_golden, example_inputs):
+    """All 708 two-strand golden rows (hetero-dimer and homodimer example runs) through drna_cofold_batch: mfe_dimer strings
+    exact, FAB = pf_dimer()[-1] within the float32 storage of the goldens, E(target) exact."""
+    for run in ("RNA_RNA_complex_design_input", "Homodimer_design_input"):
+        rows = [r for r in traj_golden if r["run"] == run]
+        tg = example_inputs[run]["sec_struct"][0]
+        eng400.set_targets([tg.replace("&", "")])
+        for b in range(0, len(rows), 128):
+            chunk = rows[b:b + 128]
+            out = eng400.cofold_batch([r["sequence"] for r in chunk])
+            for k, r in enumerate(chunk):
+                assert out["mfe_ss"][k] == r["mfe_ss"], r["sequence"]
+                assert abs(float(out["FAB"][k]) - float(r["Epf"])) < EPF_TOL_GOLDEN, r["sequence"]
+                assert int(out["Ed"][k, 0]) == round(float(r["edesired"]) * 100), r["sequence"]
+
+
+def test_cofold_vs_oracle_random(eng400, oracle):
+    rng = np.random.default_rng(2024)
+    for la, lb in ((1, 1), (2, 5), (17, 18), (40, 40), (33, 90), (100, 100)):
+        seqs = [_rand(rng, la) + "&" + _rand(rng, lb) for _ in range(4)] + [_rand(rng, la, "GC") + "&" + _rand(rng, lb, "GC")]
+        if la == lb:
+            a = _rand(rng, la)
+            seqs.append(a + "&" + a)                                 # homodimer: symmetry correction
+        eng400.set_targets(["." * (la + lb)])
+        out = eng400.cofold_batch(seqs)
+        for k, s in enumerate(seqs):
+            oss, oe = oracle.cofold_mfe(s)
+            assert (out["mfe_ss"][k], int(out["Emfe"][k])) == (oss, oe), s
+            fa, fb, fcab, fab = oracle.cofold_pf(s)
+            got = [float(out[x][k]) for x in ("FA", "FB", "FcAB", "FAB")]
+            assert max(abs(g - o) for g, o in zip(got, (fa, fb, fcab, fab))) < EPF_TOL_ORACLE, s
+            assert int(out["Ed"][k, 0]) == 0

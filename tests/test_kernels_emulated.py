@@ -124,3 +124,25 @@ def test_ragged_lengths_in_one_launch(emu, oracle, lds):
     for k, s in enumerate(seqs):
         assert (ss[k], int(E[k])) == oracle.mfe(s), s
         assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
+
+
+# ---- two strands: co-fold MFE / PF kernels and the eval kernel with the nick (fold_cofold.hpp)
+
+def test_cofold_kernels_goldens_and_random(emu, oracle, traj_golden, example_inputs):
+    for run in ("RNA_RNA_complex_design_input", "Homodimer_design_input"):
+        rows = [r for r in traj_golden if r["run"] == run][:5]
+        tg = example_inputs[run]["sec_struct"][0]
+        E, ss, F4, st, Ed = emu.cofold([r["sequence"] for r in rows], tg, nt=128)
+        assert not st.any()
+        for k, r in enumerate(rows):
+            assert ss[k] == r["mfe_ss"]
+            assert abs(F4[k, 3] - float(r["Epf"])) < 2e-6
+            assert Ed[k] == round(float(r["edesired"]) * 100)
+    rng = np.random.default_rng(11)
+    pairs = [_rand(rng, a) + "&" + _rand(rng, b) for a, b in ((1, 1), (3, 9), (12, 12), (20, 7))]
+    for s in pairs:
+        E, ss, F4, st, _ = emu.cofold([s], None, nt=64)
+        assert not st.any()
+        oss, oe = oracle.cofold_mfe(s)
+        assert (ss[0], int(E[0])) == (oss, oe), s
+        assert np.abs(F4[0] - np.array(oracle.cofold_pf(s))).max() < 1e-9, s
