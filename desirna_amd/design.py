@@ -37,7 +37,7 @@ from .sim_score import pair_table
 IUPAC = {
     'N': ['A', 'C', 'G', 'U'], 'W': ['A', 'U'], 'S': ['C', 'G'], 'M': ['A', 'C'], 'K': ['G', 'U'],
     'R': ['A', 'G'], 'Y': ['C', 'U'], 'B': ['C', 'G', 'U'], 'D': ['A', 'G', 'U'], 'H': ['A', 'C', 'U'],
-    'V': ['A', 'C', 'G'], 'C': ['C'], 'A': ['A'], 'G': ['G'], 'U': ['U'],
+    'V': ['A', 'C', 'G'], 'C': ['C'], 'A': ['A'], 'G': ['G'], 'U': ['U'], '&': ['&'],
 }
 CAN_PAIR = {'A': ['U'], 'U': ['G', 'A'], 'G': ['U', 'C'], 'C': ['G']}
 WC = {'A': 'U', 'U': 'A', 'G': 'C', 'C': 'G'}
@@ -65,8 +65,9 @@ class DesignProblem:
     """Target structure + restraints -> per-position letter sets and pairing partners (reference get_nt_list)."""
 
     def __init__(self, sec_struct, seq_restr=None, alt_sec_structs=None):
-        if "&" in sec_struct:
-            raise NotImplementedError("two-strand design inputs are not part of the GPU path yet")
+        # two strands: the '&' stays in every string as a fixed, unpaired "letter" exactly as in the reference (its positions
+        # count; seq_restr carries it too), so indices, windows and draw counts are the reference's
+        self.two_strands = "&" in sec_struct
         self.sec_struct = sec_struct
         n = len(sec_struct)
         self.seq_restr = seq_restr or "N" * n
@@ -212,7 +213,29 @@ class DesignProblem:
         pool = rng.choices([expanded, self.mutable], weights=[prob, 1 - prob])[0]
         return rng.choice(pool)
 
-    def mutate(self, seq, pos, rng):
+    def mutate(self, seq, pos, rng, oligo_state="none"):
+        """One move at `pos`; for homodimers the reference's strand-copy rules are applied afterwards (:1104-1126)."""
+        out = self._mutate(seq, pos, rng)
+        if oligo_state == "homodimer":
+            j = int(self.partner[pos])
+            ss1, ss2 = self.sec_struct.split("&")
+            s1o, s2o = seq.split("&")
+            s1m, s2m = out.split("&")
+            if j >= 0 and self.snake_of[pos] < 0 and ss1 != ss2:
+                d = sorted([pos, j])
+                a, b = d[0], d[1] - len(s1o) - 1
+                s1c = s1m[:b] + s2m[b] + s1m[b + 1:]
+                s2c = s2m[:a] + s1m[a] + s2m[a + 1:]
+                out = s1c + "&" + s2c
+                s1m, s2m = s1c, s2c
+            if ss1 == ss2:
+                if s1m != s1o:
+                    out = s1m + "&" + s1m
+                elif s2m != s2o:
+                    out = s2m + "&" + s2m
+        return out
+
+    def _mutate(self, seq, pos, rng):
         s = list(seq)
         j = int(self.partner[pos])
         if self.snake_of[pos] >= 0:                           # reference :1081-1095: move the whole snake to another state
@@ -239,14 +262,18 @@ class DesignProblem:
 
 def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-               device=0, shards=None, scorer=None, progress=None):
+               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off"):
     """Replica-exchange Monte-Carlo design of one target.  Returns dict(best=ScoreSeq, solved=bool, history=..., stats=...).
 
     ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
     own replicas and all-gathers the scores before each exchange attempt."""
     prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
     pks = "on" if set(input_file.sec_struct) - set(".()&") else "off"
-    opts = SimpleNamespace(oligo_state="none", pks=pks, subopt="off", motifs=None, param="1999",
+    if prob.two_strands:
+        oligo_state = "homodimer" if dimer == "on" else "heterodimer"       # reference DesiRNA.py:474-485
+    else:
+        oligo_state = "avoid" if oligo == "on" else "none"
+    opts = SimpleNamespace(oligo_state=oligo_state, pks=pks, subopt="off", motifs=None, param="1999",
                            scoring_f=es.parse_scoring_functions(scoring_f))
     shards = shards or rx.ReplicaShards(replicas, 0, 1)
     local = shards.local
@@ -280,7 +307,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
             for k, r in enumerate(local):
                 shelf = shelves.index(cur[k].temp_shelf)
                 pos = prob.mutation_position(cur[k].mfe_ss, shelf, replicas, tm_max, tm_min, point_mutations == "on", rngs[k])
-                props.append(prob.mutate(cur[k].sequence, pos, rngs[k]))
+                props.append(prob.mutate(cur[k].sequence, pos, rngs[k], oligo_state))
             cand = scorer.score(props)
             stats["scored"] += len(props)
             for k in range(len(local)):
@@ -322,6 +349,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
     from . import engine as _engine
     prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
+    if prob.two_strands:
+        raise NotImplementedError("two-strand inputs run through run_design (the native batched proposer is one-strand)")
     n_alt = len(input_file.alt_sec_structs) if input_file.alt_sec_structs else 0
     sf = es.parse_scoring_functions(scoring_f)
     for name, _ in sf:
@@ -464,12 +493,16 @@ def main(argv=None):
     ap.add_argument("-tm_perc_min", type=float, default=0.0, dest="tm_min")
     ap.add_argument("-seed", "--seed_number", type=int, default=0, dest="in_seed")
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
+    ap.add_argument("-d", "--dimer", default="off", choices=["off", "on"], dest="dimer", help="homodimer design (two-strand input)")
+    ap.add_argument("-oa", "--avoid_oligomerization", default="off", choices=["off", "on"], dest="oligo")
     ap.add_argument("--python-host", action="store_true", help="per-replica Python host loop instead of the native batched one")
     ap.add_argument("-o", "--outdir", default=None, help="write the reference's result files (_results.csv, _traj.csv, "
                     "_stats, _best_str, fasta files) into this directory")
     a = ap.parse_args(argv)
     inp = read_input(a.name)
-    res = (run_design if a.python_host else run_design_fast)(inp, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
+    two = "&" in inp.sec_struct or a.oligo == "on"
+    extra = dict(dimer=a.dimer, oligo=a.oligo) if two else {}
+    res = (run_design if (a.python_host or two) else run_design_fast)(inp, **extra, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
                      t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
                      seed=a.in_seed, stop_when_solved=a.sws == "on")
     if a.outdir:

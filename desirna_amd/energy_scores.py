@@ -11,12 +11,40 @@ sequence inside a forked worker.
 
 ``Edef`` is served by ``Engine.ensemble_defect`` (inside + outside recursion on the GPU).
 
-Out of scope here: two-strand inputs (``oligo_state`` homodimer / heterodimer /
-avoid) and ``-nd on`` sub-optimal search -- they raise NotImplementedError rather than silently
+Two strands (``oligo_state`` heterodimer / homodimer, and ``avoid`` = ``-o on``) go through ``Engine.cofold_batch``
+(co-fold MFE + partition function + two-strand evaluation on the GPU); the oligomer / monomer bonus terms of
+``utils/dimer_multichain_energy.py`` are computed here from its free energies.
+
+Out of scope here: ``-nd on`` sub-optimal search -- it raises NotImplementedError rather than silently
 giving different numbers.
 """
 from . import engine as _engine
 from .sim_score import batch_metrics
+
+# reference utils/dimer_multichain_energy.py:24-28
+KB = 0.001987204259
+RHO = 55.14
+TEMP = 273.15 + 37
+CONC = 1e-3
+
+
+def oligo_fraction(FA, FB, FcAB):
+    """reference dimer_multichain_energy.oligo_fraction (:30-45): fraction of strands bound in the dimer at 1 mM."""
+    import numpy as np
+    dF = FcAB - FA - FB
+    rhs = CONC / RHO * np.exp(-dF / (KB * TEMP))
+    return 1 - (np.sqrt(1 + 4 * rhs) - 1) / (2 * rhs)
+
+
+def kTlog_oligo_fraction(frac):
+    import numpy as np
+    return -KB * TEMP * np.log(frac)
+
+
+def kTlog_monomer_fraction(frac):
+    import numpy as np
+    return -KB * TEMP * np.log(1 - frac)
+
 
 AVAILABLE_SCORING_FUNCTIONS = ['Ed-Epf', '1-MCC', 'sln_Epf', 'Ed-MFE', '1-precision', '1-recall', 'Edef']
 
@@ -154,9 +182,9 @@ class ReplicaScorer:
     """Binds an engine to one design problem (target + alt structures + options) and scores batches."""
 
     def __init__(self, input_file, sim_options, max_replicas, device=0, engine=None):
-        if getattr(sim_options, "oligo_state", "none") != "none":
-            raise NotImplementedError("two-strand scoring (oligo_state=%r) is not part of the GPU path yet"
-                                      % sim_options.oligo_state)
+        self.oligo_state = getattr(sim_options, "oligo_state", "none")
+        if self.oligo_state not in ("none", "avoid", "heterodimer", "homodimer"):
+            raise ValueError("unknown oligo_state %r" % self.oligo_state)
         if getattr(sim_options, "subopt", "off") == "on":
             raise NotImplementedError("-nd on (sub-optimal search) is not part of the GPU path")
         self.input_file = input_file
@@ -180,6 +208,8 @@ class ReplicaScorer:
 
     def score(self, seqs):
         """list of sequences -> list of ScoreSeq (reference score_sequence(), once per replica)."""
+        if self.oligo_state in ("heterodimer", "homodimer"):
+            return self._score_two_strands(list(seqs))
         out = self.engine.score_batch(list(seqs), self.flags)
         metrics = batch_metrics(self.input_file.sec_struct.replace("&", "Ee"),
                                 [s.replace("&", "Ee") for s in out["mfe_ss"]])
@@ -209,6 +239,50 @@ class ReplicaScorer:
                 sc.get_edesired2(sum(energies) / len(energies))
                 sc.get_edesired2_minus_Epf(sc.Epf, sc.edesired2)
                 sc.get_scoring_function_w_alt_ss()
+            if getattr(self.sim_options, "motifs", None):
+                sc.update_scoring_function_w_motifs(score_motifs(seq, self.sim_options))
+            res.append(sc)
+        if self.oligo_state == "avoid":
+            # reference get_scoring_function_monomer (:411-418): homodimer of the sequence with itself, monomer fraction bonus
+            # (applied before the motif bonus in the reference; both are additive)
+            co = self.engine.cofold_batch([s + "&" + s for s in seqs], _engine.NEED_PF)
+            for k, sc in enumerate(res):
+                sc.oligo_fraction = float(oligo_fraction(co["FA"][k], co["FB"][k], co["FcAB"][k]))
+                sc.monomer_bonus = float(kTlog_monomer_fraction(sc.oligo_fraction))
+                sc.scoring_function = sc.scoring_function + sc.monomer_bonus
+        return res
+
+    def _score_two_strands(self, seqs):
+        """reference score_sequence() for oligo_state heterodimer / homodimer (:70-118): Epf = pf_dimer()[-1] (FAB), MFE
+        structure of mfe_dimer() with the '&' re-inserted, E(target) of the two-strand evaluation, then the oligomer bonus
+        (hetero-dimer, or homodimer with two different structures) or the monomer-fraction term (two equal structures)."""
+        out = self.engine.cofold_batch(seqs, _engine.NEED_PF | _engine.NEED_MFE | _engine.NEED_EVAL)
+        metrics = batch_metrics(self.input_file.sec_struct.replace("&", "Ee"),
+                                [s.replace("&", "Ee") for s in out["mfe_ss"]])
+        ss1, ss2 = self.input_file.sec_struct.split("&")
+        res = []
+        for k, seq in enumerate(seqs):
+            sc = ScoreSeq(sequence=seq)
+            sc.get_Epf(float(out["FAB"][k]))
+            sc.get_mfe_ss(out["mfe_ss"][k])
+            sc.get_edesired(int(out["Ed"][k, 0]) / 100.0)
+            sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
+            mcc, recall, precision = metrics[k]
+            sc.get_precision(precision)
+            sc.get_recall(recall)
+            sc.get_mcc(mcc)
+            for function, _ in self.sim_options.scoring_f:
+                if function == 'sln_Epf':
+                    sc.get_sln_Epf()
+                if function in ('Ed-MFE', 'Edef'):
+                    raise NotImplementedError("-sf %s is a one-strand quantity in the reference (RNA.fold / md defaults)" % function)
+            sc.get_scoring_function(self.sim_options.scoring_f)
+            sc.oligo_fraction = float(oligo_fraction(out["FA"][k], out["FB"][k], out["FcAB"][k]))
+            if self.oligo_state == "heterodimer" or ss1 != ss2:
+                sc.oligomer_bonus = float(kTlog_oligo_fraction(sc.oligo_fraction))
+            else:
+                sc.oligomer_bonus = float(kTlog_monomer_fraction(sc.oligo_fraction))
+            sc.scoring_function = sc.scoring_function + sc.oligomer_bonus
             if getattr(self.sim_options, "motifs", None):
                 sc.update_scoring_function_w_motifs(score_motifs(seq, self.sim_options))
             res.append(sc)

@@ -43,7 +43,7 @@ def pair_table(ss):
             o = stacks[f].pop()
             pt[o] = i
             pt[i] = o
-        elif ch not in ".-":
+        elif ch not in ".-&":          # '&': strand separator of the design drivers (an unpaired position)
             raise ValueError("unexpected character %r in structure" % ch)
     if any(stacks):
         raise ValueError("unbalanced structure: %r" % ss)

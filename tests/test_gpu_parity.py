@@ -334,3 +334,42 @@ def test_cofold_vs_oracle_random(eng400, oracle):
             got = [float(out[x][k]) for x in ("FA", "FB", "FcAB", "FAB")]
             assert max(abs(g - o) for g, o in zip(got, (fa, fb, fcab, fab))) < EPF_TOL_ORACLE, s
             assert int(out["Ed"][k, 0]) == 0
+
+
+def test_two_strand_scorer_and_design_run(eng400, oracle, traj_golden, example_inputs):
+    """oligo_state heterodimer / homodimer through ReplicaScorer (Epf = FAB, dimer MFE structure, two-strand E(target),
+    SimScore with the '&' -> 'Ee' trick, oligomer bonus from FA / FB / FcAB), -o on (monomer bonus), and a short design run."""
+    from types import SimpleNamespace
+    from desirna_amd import design
+    from desirna_amd.energy_scores import ReplicaScorer, oligo_fraction, kTlog_oligo_fraction, kTlog_monomer_fraction
+    for run, state in (("RNA_RNA_complex_design_input", "heterodimer"), ("Homodimer_design_input", "homodimer")):
+        tg = example_inputs[run]["sec_struct"][0]
+        rows = [r for r in traj_golden if r["run"] == run][:40]
+        inp = SimpleNamespace(sec_struct=tg, alt_sec_struct=None, alt_sec_structs=None)
+        opts = SimpleNamespace(oligo_state=state, subopt="off", pks="off", scoring_f=[("Ed-Epf", 1.0)], motifs={}, param="1999")
+        sc = ReplicaScorer(inp, opts, max_replicas=64, engine=eng400)
+        res = sc.score([r["sequence"] for r in rows])
+        for r, s in zip(rows, res):
+            assert s.mfe_ss == r["mfe_ss"] and abs(s.Epf - float(r["Epf"])) < EPF_TOL_GOLDEN
+            assert abs(s.edesired - float(r["edesired"])) < 1e-6 and s.mcc == float(r["one_minus_mcc"])
+            fa, fb, fcab, fab = oracle.cofold_pf(r["sequence"])
+            frac = oligo_fraction(fa, fb, fcab)
+            ss1, ss2 = tg.split("&")
+            bonus = kTlog_oligo_fraction(frac) if (state == "heterodimer" or ss1 != ss2) else kTlog_monomer_fraction(frac)
+            assert abs(s.scoring_function - (s.edesired - s.Epf + bonus)) < 1e-7
+    # -o on: one strand, monomer-fraction bonus from the homodimer of the sequence with itself
+    tg = example_inputs["Standard_design_input"]["sec_struct"][0]
+    inp = SimpleNamespace(sec_struct=tg, alt_sec_struct=None, alt_sec_structs=None)
+    opts = SimpleNamespace(oligo_state="avoid", subopt="off", pks="off", scoring_f=[("Ed-Epf", 1.0)], motifs={}, param="1999")
+    seq = "GGUGACACCGACGGCUACUGCCGUACGUGCGUCACC"
+    s = ReplicaScorer(inp, opts, max_replicas=4, engine=eng400).score([seq])[0]
+    fa, fb, fcab, fab = oracle.cofold_pf(seq + "&" + seq)
+    assert abs(s.monomer_bonus - kTlog_monomer_fraction(oligo_fraction(fa, fb, fcab))) < 1e-7
+    assert abs(s.scoring_function - (s.edesired - s.Epf + s.monomer_bonus)) < 1e-9
+    # a short hetero-dimer design run through the Python driver
+    d = example_inputs["RNA_RNA_complex_design_input"]
+    inp = SimpleNamespace(name="cx", sec_struct=d["sec_struct"][0], seq_restr=d["seq_restr"][0], seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design(inp, replicas=8, exchange=20, steps=3, seed=4)
+    b = res["best"]
+    assert b.sequence.count("&") == 1 and len(b.sequence) == len(inp.sec_struct) and b.mfe_ss.index("&") == inp.sec_struct.index("&")

@@ -102,7 +102,7 @@ def test_proposals_same_position_and_draws():
         prob = _problem(c["input"])
         rng = random.Random(c["seed"])
         pos = prob.mutation_position(c["mfe_ss"], c["shelf"], c["n_shelves"], 0.7, 0.0, True, rng)
-        mine = prob.mutate(c["sequence"], pos, rng)
+        mine = prob.mutate(c["sequence"], pos, rng, c.get("oligo_state", "none"))
         ref = c["proposed"]
         assert rng.random() == c["next_random"], c
         dm = [i for i in range(prob.n) if mine[i] != c["sequence"][i]]
@@ -120,6 +120,8 @@ def test_proposals_same_position_and_draws():
             assert mine[pos] == ref[pos]                          # first letter: sorted list, deterministic
             assert mine[j] in CAN_PAIR[mine[pos]] and ref[j] in CAN_PAIR[ref[pos]]
     assert n_exact > len(GOLD["proposals"]) // 2
+    two = [c for c in GOLD["proposals"] if c.get("oligo_state", "none") != "none"]
+    assert len(two) == 300          # hetero-dimer and homodimer inputs (strand-copy rules of the homodimer included)
 
 
 def test_output_files_byte_for_byte():

@@ -117,8 +117,9 @@ def main():
         inp = sio.read_input(os.path.join(in_dir, fn))
         G["inputs"][name] = {"name": inp.name, "sec_struct": inp.sec_struct, "seq_restr": inp.seq_restr,
                              "seed_seq": inp.seed_seq, "alt_sec_structs": inp.alt_sec_structs}
-        if "&" in inp.sec_struct:
-            continue
+        two = "&" in inp.sec_struct
+        # two-strand inputs: the RNA-RNA complex example is a hetero-dimer, the homodimer example runs with -d on
+        oligo_state = "none" if not two else ("homodimer" if "omodimer" in name else "heterodimer")
         inp.pairs = su.check_dot_bracket(inp.sec_struct)
         inp.set_target_pairs_tupl()
         if inp.alt_sec_structs is not None:
@@ -141,7 +142,7 @@ def main():
         R = 10
         temps = su.get_rep_temps(types.SimpleNamespace(replicas=R, T_min=10, T_max=150))
         opts = types.SimpleNamespace(acgu_percentages="off", point_mutations="on", tm_max=0.7, tm_min=0.0,
-                                     rep_temps_shelfs=temps, oligo_state="none", pks="off")
+                                     rep_temps_shelfs=temps, oligo_state=oligo_state, pks="off")
         for k in range(6):
             random.seed(k)
             init = su.initial_sequence_generator(nt_list, inp, opts)
@@ -149,7 +150,7 @@ def main():
         # proposals: current MFE structure = the target with its first helix opened (false negatives) and, in a second
         # variant, the exact target (no false cases)
         tgt = inp.sec_struct
-        only = "".join(c if c in "()." else "." for c in tgt)
+        only = "".join(c if c in "().&" else "." for c in tgt)
         broken = list(only)
         first_open = only.find("(")
         if first_open >= 0:
@@ -168,7 +169,7 @@ def main():
                     so.get_replica_num(1)
                     random.seed(1000 * shelf + k)
                     su.mutate_sequence(so, nt_list, opts, inp)
-                    G["proposals"].append({"input": name, "variant": vname, "sequence": base_seq, "mfe_ss": ss,
+                    G["proposals"].append({"input": name, "variant": vname, "oligo_state": oligo_state, "sequence": base_seq, "mfe_ss": ss,
                                            "shelf": shelf, "n_shelves": R, "seed": 1000 * shelf + k,
                                            "proposed": recorded["seq"], "next_random": random.random()})
     # ---- output files: reference writers run on a synthetic simulation_data list (records = vars(ScoreSeq))
