@@ -56,7 +56,28 @@ struct MfeSmemCore {
 struct MfeSmem : MfeSmemCore<MAXN> {
   int partI[PART_ITEMS * WAVE];
   int partK[PART_ITEMS * WAVE];
+  // pairable cells of a diagonal, compacted (ascending i), and the inverse map; double-buffered by diagonal parity
+  unsigned short plist[2][MAXN], cpos[2][MAXN + 2];
+  int pcnt[2];
 };
+
+// one wave: list of the cells (i, i+d) that can pair (hard constraints of the pseudoknot rounds included)
+__device__ __forceinline__ void mfe_build_plist(MfeSmem& sm, int d, int n, int lane) {
+  const int par = d & 1;
+  int cnt = 0;
+  for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+    const int i = i0 + lane;
+    const bool on = i <= n - d && pair_type(sm.Sp[i], sm.Sp[i + d]) != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) {
+      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      sm.plist[par][pos] = (unsigned short)i;
+      sm.cpos[par][i] = (unsigned short)pos;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) sm.pcnt[par] = cnt;
+}
 
 // ---- loop energies on the device (per-lane arguments; used by finalize and traceback)
 
@@ -151,30 +172,35 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
     DML[2 * ld + k] = INF;
     DML[3 * ld + k] = INF;
   }
+  if (wave == 0 && TURN + 1 < n) mfe_build_plist(sm, TURN + 1, n, lane);
   __syncthreads();
 
   for (int d = TURN + 1; d < n; d++) {
-    const int ncell = n - d;
+    const int ncell = n - d, par = d & 1;
     const int nblk = (ncell + WAVE - 1) / WAVE;
     int H = NW / nblk;
     if (H < 1) H = 1;
-    const int nitems = nblk * H;
+    // interior loops run over the PAIRABLE cells only (compact list): nblkP blocks x HI chunks of the plan
+    const int pc = sm.pcnt[par];
+    const int nblkP = (pc + WAVE - 1) / WAVE;
+    int HI = nblkP ? NW / nblkP : 1;
+    if (HI < 1) HI = 1;
+    const int nI = nblkP * HI, nK = nblk * H;
 
     // ---------------- phase A: candidate minima, lane = cell
-    for (int item = wave; item < nitems; item += NW) {
-      const int b = item / H, h = item - b * H;
-      const int i0 = b * WAVE + lane + 1;
-      const bool act = i0 <= ncell;
-      const int i = act ? i0 : ncell;
-      const int j = i + d;
-      const int t = pair_type(sm.Sp[i], sm.Sp[j]);
-      const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
-      const int ij = t * 16 + si1 * 4 + sj1;
-      int accI = INF;
-      if (__ballot(act && t != 0) != 0ull) {
+    for (int item = wave; item < nI + nK; item += NW) {
+      if (item < nI) {
+        const int cb = item / HI, h = item - cb * HI;
+        const int q = cb * WAVE + lane;
+        const int i = sm.plist[par][q < pc ? q : pc - 1];
+        const int j = i + d;
+        const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+        const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+        const int ij = t * 16 + si1 * 4 + sj1;
+        int accI = INF;
         const int tau = t > 2 ? T.TermAU : 0;
         // special kinds (stack, bulges, 1x1, 2x1, 1xn, 2x2, 2x3): strided over the chunk
-        for (int e = h; e < segG; e += H) {
+        for (int e = h; e < segG; e += HI) {
           const int u1 = P.u1[e], u2 = P.u2[e];
           const int dp = d - 2 - u1 - u2;
           if (dp <= TURN) continue;
@@ -198,20 +224,25 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
         }
         // generic interior loops: c + mismatchI(inner) precombined in CI, size term is a scalar
         int accG = INF;
-        for (int e = segG + h; e < NPLAN; e += H) {
+        for (int e = segG + h; e < NPLAN; e += HI) {
           const int u1 = P.u1[e];
           const int dp = d - 2 - u1 - P.u2[e];
           if (dp <= TURN) continue;
           accG = min(accG, CI[dp * ld + i + 1 + u1] + P.L[e]);
         }
         accI = min(accI, accG + sm.mmI[ij]);
+        sm.partI[item * WAVE + lane] = accI;
+      } else {
+        // multiloop split: fML[i,u] + fML[u+1,j], u = i + tt
+        const int it = item - nI;
+        const int b = it / H, h = it - b * H;
+        const int i0 = b * WAVE + lane + 1;
+        const int i = i0 <= ncell ? i0 : ncell;
+        int accK = INF;
+        for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
+          accK = min(accK, FML[tt * ld + i] + FML[(d - tt - 1) * ld + i + tt + 1]);
+        sm.partK[it * WAVE + lane] = accK;
       }
-      // multiloop split: fML[i,u] + fML[u+1,j], u = i + tt
-      int accK = INF;
-      for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
-        accK = min(accK, FML[tt * ld + i] + FML[(d - tt - 1) * ld + i + tt + 1]);
-      sm.partI[item * WAVE + lane] = accI;
-      sm.partK[item * WAVE + lane] = accK;
     }
     __syncthreads();
 
@@ -219,12 +250,13 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
     for (int i = tid + 1; i <= ncell; i += NT) {
       const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
       int aI = INF, aK = INF;
-      for (int h = 0; h < H; h++) {
-        aI = min(aI, sm.partI[(b * H + h) * WAVE + ln]);
-        aK = min(aK, sm.partK[(b * H + h) * WAVE + ln]);
-      }
+      for (int h = 0; h < H; h++) aK = min(aK, sm.partK[(b * H + h) * WAVE + ln]);
       const int j = i + d;
       const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      if (t) {
+        const int pos = sm.cpos[par][i];
+        for (int h = 0; h < HI; h++) aI = min(aI, sm.partI[((pos >> 6) * HI + h) * WAVE + (pos & 63)]);
+      }
       const int tau = t > 2 ? T.TermAU : 0;
       int c = INF;
       int info = 0;
@@ -249,6 +281,7 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
       DML[d * ld + i] = dec;
       FML[d * ld + i] = min(f, dec);
     }
+    if (wave == NW - 1 && d + 1 < n) mfe_build_plist(sm, d + 1, n, lane);     // list of the next diagonal
     __syncthreads();
   }
 

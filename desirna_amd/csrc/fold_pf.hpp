@@ -41,9 +41,30 @@ struct PfSmem {
   double partI[PART_ITEMS * WAVE];
   double partK[PART_ITEMS * WAVE];
   double q5[MAXN + 2];
+  // pairable cells of a diagonal, compacted (ascending i), and the inverse map; double-buffered by diagonal parity
+  unsigned short plist[2][MAXN], cpos[2][MAXN + 2];
+  int pcnt[2];
   unsigned char S[MAXN + 4];
   int flag;
 };
+
+// one wave: list of the cells (i, i+d) that can pair
+__device__ __forceinline__ void pf_build_plist(PfSmem& sm, int d, int n, int lane) {
+  const int par = d & 1;
+  int cnt = 0;
+  for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+    const int i = i0 + lane;
+    const bool on = i <= n - d && pair_type(sm.S[i], sm.S[i + d]) != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) {
+      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      sm.plist[par][pos] = (unsigned short)i;
+      sm.cpos[par][i] = (unsigned short)pos;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) sm.pcnt[par] = cnt;
+}
 
 __device__ __forceinline__ double pf_hairpin(const PfSmem& sm, const PfArgs& A, int i, int j, int t) {
   const PfTables& T = *A.T;
@@ -133,27 +154,34 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   }
   const double b1 = A.eMLb[1];
   const double sc2 = A.scale[2];
+  if (wave == 0 && TURN + 1 < n) pf_build_plist(sm, TURN + 1, n, lane);
+  __syncthreads();
 
   for (int d = TURN + 1; d < n; d++) {
-    const int ncell = n - d;
+    const int ncell = n - d, par = d & 1;
     const int nblk = (ncell + WAVE - 1) / WAVE;
     int H = NW / nblk;
     if (H < 1) H = 1;
-    const int nitems = nblk * H;
+    // interior loops run over the PAIRABLE cells only (compact list): nblkP blocks x HI chunks of the plan
+    const int pc = sm.pcnt[par];
+    const int nblkP = (pc + WAVE - 1) / WAVE;
+    int HI = nblkP ? NW / nblkP : 1;
+    if (HI < 1) HI = 1;
+    const int nI = nblkP * HI, nK = nblk * H;
 
-    for (int item = wave; item < nitems; item += NW) {
-      const int b = item / H, h = item - b * H;
-      const int i0 = b * WAVE + lane + 1;
-      const bool act = i0 <= ncell;
-      const int i = act ? i0 : ncell;
-      const int j = i + d;
-      const int t = pair_type(sm.S[i], sm.S[j]);
-      const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
-      const int ij = t * 16 + si1 * 4 + sj1;
-      double accI = 0.0;
-      if (__ballot(act && t != 0) != 0ull) {
+    for (int item = wave; item < nI + nK; item += NW) {
+      if (item < nI) {
+        const int cb = item / HI, h = item - cb * HI;
+        const int q = cb * WAVE + lane;
+        const bool act = q < pc;
+        const int i = sm.plist[par][act ? q : pc - 1];
+        const int j = i + d;
+        const int t = pair_type(sm.S[i], sm.S[j]);
+        const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+        const int ij = t * 16 + si1 * 4 + sj1;
+        double accI = 0.0;
         const double tau = t > 2 ? T.TermAU : 1.0;
-        for (int e = h; e < segG; e += H) {
+        for (int e = h; e < segG; e += HI) {
           const int u1 = P.u1[e], u2 = P.u2[e];
           const int dp = d - 2 - u1 - u2;
           if (dp <= TURN) continue;
@@ -177,31 +205,37 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
           accI += qpq * f * P.W[e];
         }
         double accG = 0.0;
-        for (int e = segG + h; e < NPLAN; e += H) {
+        for (int e = segG + h; e < NPLAN; e += HI) {
           const int u1 = P.u1[e];
           const int dp = d - 2 - u1 - P.u2[e];
           if (dp <= TURN) continue;
           accG += QBI[dp * ld + i + 1 + u1] * P.W[e];
         }
         accI += accG * sm.mmI[ij];
+        sm.partI[item * WAVE + lane] = accI;
+      } else {
+        const int it = item - nI;
+        const int b = it / H, h = it - b * H;
+        const int i0 = b * WAVE + lane + 1;
+        const int i = i0 <= ncell ? i0 : ncell;
+        double accK = 0.0;
+        for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
+          accK += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
+        sm.partK[it * WAVE + lane] = accK;
       }
-      double accK = 0.0;
-      for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
-        accK += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
-      sm.partI[item * WAVE + lane] = accI;
-      sm.partK[item * WAVE + lane] = accK;
     }
     __syncthreads();
 
     for (int i = tid + 1; i <= ncell; i += NT) {
       const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
       double aI = 0.0, aK = 0.0;
-      for (int h = 0; h < H; h++) {
-        aI += sm.partI[(b * H + h) * WAVE + ln];
-        aK += sm.partK[(b * H + h) * WAVE + ln];
-      }
+      for (int h = 0; h < H; h++) aK += sm.partK[(b * H + h) * WAVE + ln];
       const int j = i + d;
       const int t = pair_type(sm.S[i], sm.S[j]);
+      if (t) {
+        const int pos = sm.cpos[par][i];
+        for (int h = 0; h < HI; h++) aI += sm.partI[((pos >> 6) * HI + h) * WAVE + (pos & 63)];
+      }
       const double tau = t > 2 ? T.TermAU : 1.0;
       double qb = 0.0;
       int info = 0;
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
       DQ[at] = aK;
       QM[at] = m1 + aK + U;
     }
+    if (wave == NW - 1 && d + 1 < n) pf_build_plist(sm, d + 1, n, lane);     // list of the next diagonal
     __syncthreads();
   }
 
