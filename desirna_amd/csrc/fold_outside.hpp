@@ -112,24 +112,31 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
   }
   __syncthreads();
 
+  if (wave == 0 && n - 1 >= TURN + 1) pf_build_plist(sm, n - 1, n, lane);
+  __syncthreads();
+
   for (int d = n - 1; d >= TURN + 1; d--) {
-    const int ncell = n - d;
+    const int ncell = n - d, par = d & 1;
     const int nblk = (ncell + WAVE - 1) / WAVE;
     int H = NW / nblk;
     if (H < 1) H = 1;
-    const int nitems = nblk * H;
+    // the interior-loop pull runs over the PAIRABLE cells only (compact list, as in pf_kernel)
+    const int pc = sm.pcnt[par];
+    const int nblkP = (pc + WAVE - 1) / WAVE;
+    int HI = nblkP ? NW / nblkP : 1;
+    if (HI < 1) HI = 1;
+    const int nI = nblkP * HI, nK = nblk * H;
 
-    for (int item = wave; item < nitems; item += NW) {
-      const int b = item / H, h = item - b * H;
-      const int i0 = b * WAVE + lane + 1;
-      const bool act = i0 <= ncell;
-      const int i = act ? i0 : ncell;
-      const int j = i + d;
-      const int info = INFO[d * ld + i];          // 0 = (i,j) cannot pair
-      double accI = 0.0;
-      if (__ballot(act && info != 0) != 0ull) {
+    for (int item = wave; item < nI + nK; item += NW) {
+      if (item < nI) {
+        const int cb = item / HI, h = item - cb * HI;
+        const int q = cb * WAVE + lane;
+        const int i = sm.plist[par][q < pc ? q : pc - 1];
+        const int j = i + d;
+        const int info = INFO[d * ld + i];
         const int t2 = info >> 4;                 // rtype of (i,j) seen as the inner pair
-        for (int e = h; e < segG; e += H) {
+        double accI = 0.0;
+        for (int e = h; e < segG; e += HI) {
           const int u1 = P.u1[e], u2 = P.u2[e];
           const bool ok = i - 1 - u1 >= 1 && j + 1 + u2 <= n;
           const int io = ok ? i - 1 - u1 : 1, jo = ok ? j + 1 + u2 : n;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
           if (ok) accI += o * f * P.W[e];
         }
         double accG = 0.0;
-        for (int e = segG + h; e < NPLAN; e += H) {
+        for (int e = segG + h; e < NPLAN; e += HI) {
           const int u1 = P.u1[e], u2 = P.u2[e];
           const bool ok = i - 1 - u1 >= 1 && j + 1 + u2 <= n;
           const int io = ok ? i - 1 - u1 : 1, jo = ok ? j + 1 + u2 : n;
@@ -163,19 +170,25 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
           if (ok) accG += o * P.W[e];
         }
         accI += accG * sm.mmI[info];
-        if (info == 0) accI = 0.0;
+        sm.partI[item * WAVE + lane] = accI;
+      } else {
+        const int it = item - nI;
+        const int b = it / H, h = it - b * H;
+        const int i0 = b * WAVE + lane + 1;
+        const bool act = i0 <= ncell;
+        const int i = act ? i0 : ncell;
+        const int j = i + d;
+        // Om[i,j] = sum_s A[i, j+1+s] qm1[j+1, j+1+s]
+        double accA1 = 0.0;
+        const int smax = act ? n - j - 1 : -1;
+        for (int s = TURN + 1 + h; s <= smax; s += H) accA1 += AT[(d + 1 + s) * ld + i] * QM1[s * ld + j + 1];
+        // sum_t A[i-t, j] qm[i-t, i-1]
+        double accA2 = 0.0;
+        const int tmax = act ? i - 1 : -1;
+        for (int t = TURN + 2 + h; t <= tmax; t += H) accA2 += AT[(d + t) * ld + i - t] * QM[(t - 1) * ld + i - t];
+        sm.partK[it * WAVE + lane] = accA1;
+        sm.partM[it * WAVE + lane] = accA2;
       }
-      // Om[i,j] = sum_s A[i, j+1+s] qm1[j+1, j+1+s]
-      double accA1 = 0.0;
-      const int smax = act ? n - j - 1 : -1;
-      for (int s = TURN + 1 + h; s <= smax; s += H) accA1 += AT[(d + 1 + s) * ld + i] * QM1[s * ld + j + 1];
-      // sum_t A[i-t, j] qm[i-t, i-1]
-      double accA2 = 0.0;
-      const int tmax = act ? i - 1 : -1;
-      for (int t = TURN + 2 + h; t <= tmax; t += H) accA2 += AT[(d + t) * ld + i - t] * QM[(t - 1) * ld + i - t];
-      sm.partI[item * WAVE + lane] = accI;
-      sm.partK[item * WAVE + lane] = accA1;
-      sm.partM[item * WAVE + lane] = accA2;
     }
     __syncthreads();
 
@@ -183,13 +196,16 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
       const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
       double aI = 0.0, a1 = 0.0, a2 = 0.0;
       for (int h = 0; h < H; h++) {
-        aI += sm.partI[(b * H + h) * WAVE + ln];
         a1 += sm.partK[(b * H + h) * WAVE + ln];
         a2 += sm.partM[(b * H + h) * WAVE + ln];
       }
       const int j = i + d;
       const int at = d * ld + i;
       const int t = pair_type(sm.S[i], sm.S[j]);
+      if (t) {
+        const int pos = sm.cpos[par][i];
+        for (int h = 0; h < HI; h++) aI += sm.partI[((pos >> 6) * HI + h) * WAVE + (pos & 63)];
+      }
       const double tau = t > 2 ? T.TermAU : 1.0;
       const double om = a1;
       const double V = i > 1 ? b1 * OMV[(d + 1) * ld + i - 1] : 0.0;
@@ -210,6 +226,7 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
       OMV[at] = om + V;
       OM1[at] = om1;
     }
+    if (wave == NW - 1 && d - 1 >= TURN + 1) pf_build_plist(sm, d - 1, n, lane);     // list of the next diagonal
     __syncthreads();
   }
 
