@@ -67,6 +67,13 @@ struct drna_engine {
   int* d_rpt_off = nullptr;
   std::vector<int> rt_len;
   double* d_F4 = nullptr;   // co-fold free energies (FA, FB, FcAB, FAB per pair)
+  // host-mapped staging of the host-buffer entry point: the kernels read the sequences from and write their results to
+  // pinned host memory directly, so a batch costs no hipMemcpy round trips (12.8 KB in, 13.6 KB out at R=64, L=200)
+  char *hm_seqs = nullptr, *hm_ss = nullptr, *dm_seqs = nullptr, *dm_ss = nullptr;
+  double *hm_Epf = nullptr, *dm_Epf = nullptr;
+  int32_t *hm_Emfe = nullptr, *dm_Emfe = nullptr, *hm_Ed = nullptr, *dm_Ed = nullptr;
+  size_t hm_Ed_cap = 0;
+  bool zero_copy = true;
   std::string err;
 };
 
@@ -128,6 +135,15 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipHostMalloc((void**)&e->h_status, (size_t)2 * max_R * sizeof(int32_t), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void**)&e->d_status, e->h_status, 0));
   memset(e->h_status, 0, (size_t)2 * max_R * sizeof(int32_t));
+  if (const char* z = getenv("DRNA_STAGING")) e->zero_copy = std::string(z) != "device";
+  HIP_TRY(hipHostMalloc((void**)&e->hm_seqs, (size_t)max_R * max_L, hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void**)&e->hm_ss, (size_t)max_R * max_L, hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void**)&e->hm_Epf, (size_t)max_R * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void**)&e->hm_Emfe, (size_t)max_R * sizeof(int32_t), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->dm_seqs, e->hm_seqs, 0));
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->dm_ss, e->hm_ss, 0));
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->dm_Epf, e->hm_Epf, 0));
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->dm_Emfe, e->hm_Emfe, 0));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_mfe, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_pf, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_eval, hipStreamNonBlocking));
@@ -159,6 +175,9 @@ extern "C" void drna_destroy(drna_engine* e) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
+  void* hm[] = {e->hm_seqs, e->hm_ss, e->hm_Epf, e->hm_Emfe, e->hm_Ed};
+  for (void* b : hm)
+    if (b) (void)hipHostFree(b);
   hipStream_t ss[] = {e->s_mfe, e->s_pf, e->s_eval};
   for (hipStream_t s : ss)
     if (s) (void)hipStreamDestroy(s);
@@ -314,6 +333,27 @@ extern "C" int drna_score_batch(drna_engine* e, int R, int L, const char* seqs, 
     return DRNA_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(e->device));
+  if (e->zero_copy) {
+    const size_t ned = (size_t)R * (e->n_targets > 0 ? e->n_targets : 1);
+    if (want_ev && e->hm_Ed_cap < ned) {
+      if (e->hm_Ed) (void)hipHostFree(e->hm_Ed);
+      e->hm_Ed = nullptr; e->hm_Ed_cap = 0;
+      const size_t cap = (size_t)e->max_R * (e->n_targets > 0 ? e->n_targets : 1);
+      HIP_TRY(hipHostMalloc((void**)&e->hm_Ed, cap * sizeof(int32_t), hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer((void**)&e->dm_Ed, e->hm_Ed, 0));
+      e->hm_Ed_cap = cap;
+    }
+    std::memcpy(e->hm_seqs, seqs, (size_t)R * L);
+    int rc = drna_score_batch_device(e, R, L, e->dm_seqs, flags, e->dm_Epf, e->dm_Emfe, e->dm_ss, e->dm_Ed);
+    if (rc != DRNA_OK) return rc;
+    if (want_pf) std::memcpy(Epf, e->hm_Epf, (size_t)R * sizeof(double));
+    if (want_mfe) {
+      std::memcpy(Emfe, e->hm_Emfe, (size_t)R * sizeof(int32_t));
+      std::memcpy(mfe_ss, e->hm_ss, (size_t)R * L);
+    }
+    if (want_ev) std::memcpy(Ed, e->hm_Ed, ned * sizeof(int32_t));
+    return DRNA_OK;
+  }
   HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
   int rc = drna_score_batch_device(e, R, L, e->d_seqs, flags, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed);
   if (rc != DRNA_OK) return rc;
