@@ -20,6 +20,7 @@
 namespace drna {
 
 constexpr int PF_FAST_NMAX = 200;
+constexpr int PEC = 3;          // pairable cells per bulge / 1xn work item
 constexpr int PGSLOTS = 10;       // tower entries per pinned wave: 28 residues over 3 waves
 constexpr int PNG = 3;            // sweep waves pinned to one 64-tower block
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // descriptor only for ld >= 48)
     const int kssh = (ncell <= 32 && ld >= 48) ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
     const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
-    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 1) >> 1,
+    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + PEC - 1) / PEC,
               nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
     const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
@@ -346,24 +347,46 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
         }
       } else if (it < nK + nE) {
-        const int q = 2 * (it - nK);
-        const bool two = q + 1 < pcnt;
-        const int pe0 = sm.plist[par][as_vector(q)], pe1 = sm.plist[par][as_vector(two ? q + 1 : q)];
-        const int i0 = pe0 & 255, ij0 = pe0 >> 8, i1 = pe1 & 255, ij1 = pe1 >> 8;
-        const double w00 = sm.qbi[b_off + i0], w01 = sm.qbi[o_off + i0];
-        const double w10 = sm.qbi[b_off + i1], w11 = sm.qbi[o_off + i1];
-        const int f00 = sm.info[b_off + i0], f01 = sm.info[o_off + i0];
-        const int f10 = sm.info[b_off + i1], f11 = sm.info[o_off + i1];
-        const double r00 = sm.rbul[f00], r01 = sm.r1n[f01], r10 = sm.rbul[f10], r11 = sm.r1n[f11];
-        const double m0 = sm.mm1n[ij0], m1 = sm.mm1n[ij1];
+        // PEC pairable cells per item, all loads of a stage issued before the first is consumed
+        const int q = PEC * (it - nK);
+        int i0[PEC], ij[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; c++) {
+          const int pe = sm.plist[par][as_vector(q + c < pcnt ? q + c : q)];
+          i0[c] = pe & 255; ij[c] = pe >> 8;
+        }
         const double b_W = sm.eWb[lane], o_W = sm.eWo[lane];
-        double v0 = (b_ok ? w00 * r00 * b_W : 0.0) * ((ij0 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w01 * r01 * o_W : 0.0) * m0;
-        double v1 = (b_ok ? w10 * r10 * b_W : 0.0) * ((ij1 >> 4) > 2 ? eTau : 1.0) + (o_ok ? w11 * r11 * o_W : 0.0) * m1;
-        v0 = wave_total_f64_lane63(v0);
-        v1 = wave_total_f64_lane63(v1);
+        double wb[PEC], wo[PEC];
+        int fb[PEC], fo[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; c++) {
+          wb[c] = sm.qbi[b_off + i0[c]]; wo[c] = sm.qbi[o_off + i0[c]];
+          fb[c] = sm.info[b_off + i0[c]]; fo[c] = sm.info[o_off + i0[c]];
+        }
+        double rb[PEC], ro[PEC], mo[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; c++) { rb[c] = sm.rbul[fb[c]]; ro[c] = sm.r1n[fo[c]]; mo[c] = sm.mm1n[ij[c]]; }
+        double v[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; c++)
+          v[c] = (b_ok ? wb[c] * rb[c] * b_W : 0.0) * ((ij[c] >> 4) > 2 ? eTau : 1.0) + (o_ok ? wo[c] * ro[c] * o_W : 0.0) * mo[c];
+        // PEC interleaved wave sums (lane 63 ends with the totals)
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x111, 0xF>(v[c]);
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x112, 0xF>(v[c]);
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x114, 0xF>(v[c]);
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x118, 0xF>(v[c]);
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x142, 0xA>(v[c]);
+#pragma unroll
+        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x143, 0xC>(v[c]);
         if (lane == WAVE - 1) {
-          sm.accE[par][i0 + slot0] = v0;
-          if (two) sm.accE[par][i1 + slot0] = v1;
+#pragma unroll
+          for (int c = 0; c < PEC; c++)
+            if (q + c < pcnt) sm.accE[par][i0[c] + slot0] = v[c];
         }
       } else {
         const int xi = it - nK - nE;
