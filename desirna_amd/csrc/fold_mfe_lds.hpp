@@ -393,6 +393,9 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
               w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 255) + i0];
             }
             const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij];
+            int tb[4];                                           // inner-side 1xn mismatch terms: one more LDS stage
+#pragma unroll
+            for (int k = 0; k < 4; k++) tb[k] = sm.mm1np[w[k + 4] & 127];
             int v = INF;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -401,7 +404,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             }
 #pragma unroll
             for (int k = 4; k < 8; k++) {
-              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + sm.mm1np[w[k] & 127] + outer_o;
+              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + tb[k - 4] + outer_o;
               v = min(v, ok[k] ? e : INF);
             }
             v = dpp_min_i32<0x111, 0xF>(v);
