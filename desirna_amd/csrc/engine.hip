@@ -889,6 +889,99 @@ extern "C" int drna_metropolis_batch(int R, const double* score_o, const double*
   return DRNA_OK;
 }
 
+// ---------------------------------------------------------------- the whole Monte-Carlo inner loop of one exchange step
+
+extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char* target, const int32_t* partner,
+                           const unsigned char* allowed_mask, const int32_t* snake_of, int n_snakes, const int32_t* snake_off,
+                           const int32_t* snake_nodes, const int32_t* snake_nstates, const char* snake_states,
+                           const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
+                           const double* temps, double Lconst, int n_terms, const int32_t* term_id, const double* term_w,
+                           uint32_t flags, uint64_t* rng_state, char* seqs, char* mfe_ss, double* score, double* mcc1,
+                           double* Epf, double* Ed, int64_t* counters, char* best_seq, char* best_ss, double* best) {
+  using namespace drna_host;
+  if (!e) return DRNA_ERR_ARG;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || n_iter < 0 || !target || !allowed_mask || !shelf_index || !temps ||
+      n_terms < 1 || !term_id || !term_w || !rng_state || !seqs || !mfe_ss || !score || !mcc1 || !Epf || !Ed || !counters ||
+      !best_seq || !best_ss || !best || e->n_targets < 1 || e->L_targets != L) {
+    e->err = "drna_mc_run: bad argument (targets installed with drna_set_targets for this L; every state array given)";
+    return DRNA_ERR_ARG;
+  }
+  const int nt = e->n_targets;
+  std::vector<char> prop((size_t)R * L), pss((size_t)R * L);
+  std::vector<double> pEpf(R), pscore(R), pmcc(R), prec(R), pprec(R);
+  std::vector<int32_t> pEmfe(R), pEd((size_t)R * nt);
+  std::vector<unsigned char> acc(R), better(R);
+  std::vector<int> pr(L), pq(L);
+  if (!pair_table(target, L, pr.data())) return DRNA_ERR_STRUCTURE;
+  for (int it = 0; it < n_iter; it++) {
+    int rc = propose_impl(R, L, target, partner, allowed_mask, n_snakes > 0 ? snake_of : nullptr, snake_off, snake_nodes,
+                          snake_nstates, snake_states, seqs, mfe_ss, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state,
+                          prop.data());
+    if (rc != DRNA_OK) { e->err = "drna_mc_run: proposal failed"; return rc; }
+    rc = drna_score_batch(e, R, L, prop.data(), flags | DRNA_NEED_PF | DRNA_NEED_MFE | DRNA_NEED_EVAL, pEpf.data(), pEmfe.data(),
+                          pss.data(), pEd.data());
+    if (rc != DRNA_OK) return rc;
+    for (int r = 0; r < R; r++) {
+      // SimScore of the proposal's structure against the target (utils/sim_score.py:62-147)
+      if (!pair_table(pss.data() + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
+      long tp = 0, fp = 0, fn = 0, tn = 0;
+      for (int i = 0; i < L; i++) {
+        if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }
+        else if (pr[i] == -1) fp++;
+        else fn++;
+      }
+      double num, den;
+      if (tp == 0 && fp == 0 && fn == 0 && tn != 0) { num = 1; den = 1; }
+      else {
+        num = (double)(tp * tn) - (double)(fp * fn);
+        den = std::sqrt((double)((tp + fp) * (tp + fn) * (tn + fn) * (tn + fp)));
+      }
+      const double mcc = py_round3(num / (den + 0.00001));
+      const double rec = py_round3((double)tp / ((double)(tp + fn) + 0.001));
+      const double pre = py_round3((double)tp / ((double)(tp + fp) + 0.001));
+      const double ed = pEd[(size_t)r * nt] / 100.0;
+      // -sf terms (utils/energy_scores.py:376-398): 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall
+      double tot = 0.0;
+      for (int k = 0; k < n_terms; k++) {
+        double v;
+        switch (term_id[k]) {
+          case 0: v = ed - pEpf[r]; break;
+          case 1: v = (1 - mcc) * 10; break;
+          case 2: v = (pEpf[r] + 0.3759 * L + 5.7534) / 10; break;
+          case 3: v = ed - pEmfe[r] / 100.0; break;
+          case 4: v = (1 - pre) * 10; break;
+          case 5: v = (1 - rec) * 10; break;
+          default: e->err = "drna_mc_run: unknown scoring term"; return DRNA_ERR_ARG;
+        }
+        tot += v * term_w[k];
+      }
+      if (nt > 1) {                                           // alternative structures (:98-102)
+        double sum = 0.0;
+        for (int t = 1; t < nt; t++) sum += pEd[(size_t)r * nt + t] / 100.0;
+        tot += sum / (nt - 1) - pEpf[r];
+      }
+      pscore[r] = tot; pmcc[r] = 1 - mcc;
+    }
+    rc = drna_metropolis_batch(R, score, pscore.data(), temps, Lconst, rng_state, acc.data(), better.data());
+    if (rc != DRNA_OK) return rc;
+    for (int r = 0; r < R; r++) {
+      if (acc[r]) {
+        std::memcpy(seqs + (size_t)r * L, prop.data() + (size_t)r * L, (size_t)L);
+        std::memcpy(mfe_ss + (size_t)r * L, pss.data() + (size_t)r * L, (size_t)L);
+        score[r] = pscore[r]; mcc1[r] = pmcc[r]; Epf[r] = pEpf[r]; Ed[r] = pEd[(size_t)r * nt] / 100.0;
+        counters[0]++;
+        if (better[r]) counters[1]++;
+        if (mcc1[r] < best[0] || (mcc1[r] == best[0] && score[r] < best[1])) {
+          best[0] = mcc1[r]; best[1] = score[r]; best[2] = Epf[r]; best[3] = Ed[r];
+          std::memcpy(best_seq, seqs + (size_t)r * L, (size_t)L);
+          std::memcpy(best_ss, mfe_ss + (size_t)r * L, (size_t)L);
+        }
+      } else counters[2]++;
+    }
+  }
+  return DRNA_OK;
+}
+
 #if defined(DRNA_STAMPS) || defined(DRNA_STAMPS_API)
 // diagnostic build only: copy `count` int32 of the MFE workspace starting at int32 offset `off`
 extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, int32_t* out) {

@@ -343,7 +343,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
 
 def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                     scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-                    device=0, engine=None, keep_records=True):
+                    device=0, engine=None, keep_records=True, native_loop=None):
     """Same loop as :func:`run_design` with the per-replica host work in native code and no per-step Python objects:
     proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.
     Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
@@ -418,6 +418,12 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         return out
 
     simulation_data = records(0) if keep_records else []
+    if native_loop is None:
+        native_loop = True
+    native_loop = native_loop and all(name in eng.TERM_IDS for name, _ in sf)   # Edef needs the outside kernel: Python loop
+    cur = np.ascontiguousarray(cur); cur_ss = np.ascontiguousarray(cur_ss)
+    cur_score = np.ascontiguousarray(cur_score, dtype=np.float64); cur_mcc = np.ascontiguousarray(cur_mcc, dtype=np.float64)
+    cur_epf = np.ascontiguousarray(cur_epf, dtype=np.float64); cur_ed = np.ascontiguousarray(cur_ed, dtype=np.float64)
     t_start = time.time()
     step = 0
     solved = best["mcc"] == 0.0
@@ -432,7 +438,19 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         step += 1
         rng_state = np.arange(R, dtype=np.uint64)                # re-seeded with the replica index every exchange step
         shelf_idx = np.searchsorted(shelves, temps).astype(np.int32)
-        for _ in range(exchange):
+        if native_loop:
+            # the whole inner loop of the exchange step in native code (drna_mc_run): one call, no per-iteration Python
+            state = dict(seqs=cur, mfe_ss=cur_ss, score=cur_score, mcc1=cur_mcc, Epf=cur_epf, Ed=cur_ed)
+            counters = np.zeros(3, dtype=np.int64)
+            bst = dict(seq=np.frombuffer(best["sequence"].encode(), dtype=np.uint8).copy(),
+                       ss=np.frombuffer(best["mfe_ss"].encode(), dtype=np.uint8).copy(),
+                       vals=np.array([best["mcc"], best["scoring_function"], best["Epf"], best["edesired"]], dtype=np.float64))
+            eng.mc_run(prob, exchange, shelf_idx, R, tm_max, tm_min, targeted, temps, sf, flags, rng_state, state, counters, bst)
+            best = dict(sequence=bst["seq"].tobytes().decode(), mfe_ss=bst["ss"].tobytes().decode(), mcc=float(bst["vals"][0]),
+                        scoring_function=float(bst["vals"][1]), Epf=float(bst["vals"][2]), edesired=float(bst["vals"][3]))
+            stats["acc_mc"] += int(counters[0]); stats["acc_mc_better"] += int(counters[1]); stats["rej_mc"] += int(counters[2])
+            stats["scored"] += R * exchange
+        for _ in range(0 if native_loop else exchange):
             if prob.snakes or n_alt:
                 prop = hk.propose_alt(prob, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
             else:

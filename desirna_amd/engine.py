@@ -24,7 +24,7 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run")
 
 
 class EngineError(RuntimeError):
@@ -70,6 +70,9 @@ def load_library(path=None):
     L.drna_score_ragged.argtypes = [vp, ci, vp, C.c_char_p, vp, u32, vp, vp, vp, vp]
     L.drna_cofold_batch.restype = ci
     L.drna_cofold_batch.argtypes = [vp, ci, ci, ci, C.c_char_p, u32, vp, vp, vp, vp]
+    L.drna_mc_run.restype = ci
+    L.drna_mc_run.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, C.c_double, C.c_double, ci, vp,
+                              C.c_double, ci, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -215,6 +218,29 @@ class Engine:
             out.update(FA=F4[:, 0], FB=F4[:, 1], FcAB=F4[:, 2], FAB=F4[:, 3])
         return out
 
+    TERM_IDS = {"Ed-Epf": 0, "1-MCC": 1, "sln_Epf": 2, "Ed-MFE": 3, "1-precision": 4, "1-recall": 5}
+
+    def mc_run(self, prob, n_iter, shelf_index, n_shelves, tm_max, tm_min, targeted, temps, scoring_f, flags, rng_state, state,
+               counters, best, L_const=504.12):
+        """n_iter Monte-Carlo iterations of all replicas in native code (drna_mc_run).  `state` holds the arrays seqs, mfe_ss
+        (uint8 R x L), score, mcc1, Epf, Ed (float64 R); `best` holds seq, ss (uint8 L) and vals (float64 4); all updated in place."""
+        pk = getattr(prob, "_native_pack", None)
+        if pk is None:
+            HostKernels._pack(prob)
+            pk = prob._native_pack
+        am, partner, snake_of, off, nodes, nst, chars = pk
+        R, L = state["seqs"].shape
+        ids = np.array([self.TERM_IDS[n] for n, _ in scoring_f], dtype=np.int32)
+        ws = np.array([w for _, w in scoring_f], dtype=np.float64)
+        sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
+        tt = np.ascontiguousarray(temps, dtype=np.float64)
+        p = lambda a: a.ctypes.data
+        self._check(self._L.drna_mc_run(self._h, R, L, int(n_iter), prob.sec_struct.encode("ascii"), p(partner), p(am), p(snake_of),
+                                        len(prob.snakes), p(off), p(nodes), p(nst), p(chars), p(sh), int(n_shelves), float(tm_max),
+                                        float(tm_min), int(bool(targeted)), p(tt), float(L_const), len(ids), p(ids), p(ws), int(flags),
+                                        p(rng_state), p(state["seqs"]), p(state["mfe_ss"]), p(state["score"]), p(state["mcc1"]),
+                                        p(state["Epf"]), p(state["Ed"]), p(counters), p(best["seq"]), p(best["ss"]), p(best["vals"])))
+
     def ensemble_defect(self, seqs, want_bpp=False):
         """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
         utils/energy_scores.py:362-374).  Returns float64[R]; with want_bpp also the (R, L+1, L+1) base-pair
@@ -262,6 +288,21 @@ class HostKernels:
     def __init__(self, lib=None):
         self._L = load_library(lib)
 
+    @staticmethod
+    def _pack(prob):
+        """arrays of a design.DesignProblem in the layout of drna_propose_batch_alt / drna_mc_run (cached on the problem)"""
+        am = np.array([sum(1 << "ACGU".index(c) for c in a) for a in prob.allowed], dtype=np.uint8)
+        partner = np.ascontiguousarray(prob.partner, dtype=np.int32)
+        snake_of = np.ascontiguousarray(prob.snake_of, dtype=np.int32)
+        off, nodes, nst, chars = [0], [], [], b""
+        for nd, states in prob.snakes:
+            nodes += list(nd)
+            off.append(len(nodes))
+            nst.append(len(states))
+            chars += "".join(states).encode() + b"." * (len(nd) * (4 - len(states)))
+        prob._native_pack = (am, partner, snake_of, np.array(off, dtype=np.int32), np.array(nodes or [0], dtype=np.int32),
+                             np.array(nst or [0], dtype=np.int32), np.frombuffer(chars or b".", dtype=np.uint8).copy())
+
     def simscore(self, ref, queries_u8):
         """ref: reference structure string ('&' -> 'Ee' already applied); queries_u8: (R, L) uint8.
         Returns rounded (mcc, recall, precision) arrays exactly as the reference's SimScore computes them."""
@@ -297,18 +338,8 @@ class HostKernels:
         ss = np.ascontiguousarray(ss_u8, dtype=np.uint8)
         pk = getattr(prob, "_native_pack", None)
         if pk is None:
-            am = np.array([sum(1 << "ACGU".index(c) for c in a) for a in prob.allowed], dtype=np.uint8)
-            partner = np.ascontiguousarray(prob.partner, dtype=np.int32)
-            snake_of = np.ascontiguousarray(prob.snake_of, dtype=np.int32)
-            off, nodes, nst, chars = [0], [], [], b""
-            for nd, states in prob.snakes:
-                nodes += list(nd)
-                off.append(len(nodes))
-                nst.append(len(states))
-                chars += "".join(states).encode() + b"." * (len(nd) * (4 - len(states)))
-            pk = (am, partner, snake_of, np.array(off, dtype=np.int32), np.array(nodes or [0], dtype=np.int32),
-                  np.array(nst or [0], dtype=np.int32), np.frombuffer(chars or b".", dtype=np.uint8).copy())
-            prob._native_pack = pk
+            HostKernels._pack(prob)
+            pk = prob._native_pack
         am, partner, snake_of, off, nodes, nst, chars = pk
         sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
         assert rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
@@ -332,5 +363,5 @@ class HostKernels:
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
             raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run")
         return acc.astype(bool), bet.astype(bool)

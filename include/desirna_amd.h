@@ -193,6 +193,25 @@ int drna_propose_batch_alt(int R, int L, const char *target, const int32_t *part
 int drna_metropolis_batch(int R, const double *score_o, const double *score_m, const double *temps, double Lconst,
                           uint64_t *rng_state, unsigned char *accept, unsigned char *better);
 
+/*
+ * drna_mc_run: n_iter Monte-Carlo iterations of ALL replicas without returning to the caller -- the body of
+ * single_replica_design (utils/replica_exchange_monte_carlo.py:176-210) for R replicas in lock-step: proposal
+ * (drna_propose_batch[_alt] rules; partner / snake arrays may be NULL / 0 for plain targets), scoring of the R proposals on the
+ * GPU (drna_score_batch with flags | PF | MFE | EVAL against the structures of drna_set_targets), SimScore, the -sf sum
+ * (term_id: 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall; weights term_w; + mean E(alt) - Epf when
+ * alternative structures are installed), Metropolis acceptance, state update.
+ *   in/out per replica: seqs, mfe_ss (R*L chars), score, mcc1 (= 1 - MCC), Epf, Ed (kcal/mol), rng_state
+ *   counters[3] += accepted, accepted-better, rejected;  best[4] = {1-MCC, score, Epf, Ed} and best_seq / best_ss (L chars)
+ *   are replaced whenever an accepted state is better (lower 1-MCC, then lower score)
+ */
+int drna_mc_run(drna_engine *e, int R, int L, int n_iter, const char *target, const int32_t *partner,
+                const unsigned char *allowed_mask, const int32_t *snake_of, int n_snakes, const int32_t *snake_off,
+                const int32_t *snake_nodes, const int32_t *snake_nstates, const char *snake_states,
+                const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min, int targeted, const double *temps,
+                double Lconst, int n_terms, const int32_t *term_id, const double *term_w, uint32_t flags,
+                uint64_t *rng_state, char *seqs, char *mfe_ss, double *score, double *mcc1, double *Epf, double *Ed,
+                int64_t *counters, char *best_seq, char *best_ss, double *best);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,3 +255,18 @@ def test_design_run_writes_reference_result_files(oracle, tmp_path):
     assert hdr[:5] == ["sequence", "scoring_function", "replica_num", "temp_shelf", "sim_step"]
     assert ok == res["solved"] and top[0]["mcc"] == min(r["mcc"] for r in res["simulation_data"])
     assert open(tmp_path / "out_best_str").read().startswith(">ete1,%s," % ok)
+
+
+@pytest.mark.gpu
+def test_native_mc_loop_equals_python_loop_on_gpu(eterna_targets):
+    """drna_mc_run (the whole inner loop of an exchange step in native code) replays exactly what the per-iteration Python loop
+    over the same native helpers does: same random streams, same accept decisions, same best sequence."""
+    tg = eterna_targets["eteV1_92.txt"]
+    inp = SimpleNamespace(name="ete92", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    a = design.run_design_fast(inp, replicas=16, exchange=25, steps=3, seed=7, native_loop=True, scoring_f="Ed-Epf:0.9")
+    b = design.run_design_fast(inp, replicas=16, exchange=25, steps=3, seed=7, native_loop=False, scoring_f="Ed-Epf:0.9")
+    assert a["best"].sequence == b["best"].sequence and a["best"].scoring_function == b["best"].scoring_function
+    for k in ("acc_mc", "acc_mc_better", "rej_mc", "acc_re", "rej_re", "scored"):
+        assert a["stats"][k] == b["stats"][k], k
+    assert [r["sequence"] for r in a["simulation_data"]] == [r["sequence"] for r in b["simulation_data"]]
