@@ -12,8 +12,8 @@
 //   * dangling neighbours count only inside a strand;
 //   * MFE = min(f5[n] + DuplexInit, fcA[1] + fcB[n]); Q = (q5[n] - QA QB) expDuplexInit [/ 2 for two equal strands]
 //     + QA QB.
-// First correct version: one lane per cell, serial candidate loops, every table in HBM/L2 (diagonal-major like
-// fold_mfe.hpp); the traceback is wave 0's, candidates in ViennaRNA's order (interior loops, nick, multiloop).
+// One wave per cell (the lanes share the interior-loop shapes and the split points, wave minimum / fixed-order wave sum),
+// every table in HBM/L2 (diagonal-major like fold_mfe.hpp); the traceback is wave 0's, candidates in ViennaRNA's order (interior loops, nick, multiloop).
 #pragma once
 #include "fold_mfe.hpp"
 #include "fold_pf.hpp"
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(NT) void cofold_mfe_kernel(CoArgs A) {
 
   for (int d = 1; d < n; d++) {
     const int ncell = n - d;
-    for (int i = tid + 1; i <= ncell; i += NT) {
+    // one wave per cell: the lanes share the 496 interior-loop shapes and the split points, then fold with a wave minimum
+    for (int i = wave + 1; i <= ncell; i += NT / WAVE) {
       const int j = i + d;
       const bool same = co_same(i, j, cut);
       const int t = (d > TURN || !same) ? pair_type(sm.S[i], sm.S[j]) : 0;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(NT) void cofold_mfe_kernel(CoArgs A) {
         const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
         if (same) c = mfe_hairpin_e(sm, T, A.hp_len[d - 1], i, j, t);
         else c = tau + co_endstem(sm.mmExt, sm, rtype_of(t), adj_j, sj1, adj_i, si1) + sm.fcA[i + 1] + sm.fcB[j - 1];
-        for (int e = 0; e < NPLAN; e++) {
+        int m = INF;
+        for (int e = lane; e < NPLAN; e += WAVE) {
           const int u1 = P.u1[e], u2 = P.u2[e];
           const int dp = d - 2 - u1 - u2;
           if (dp < 1) continue;
@@ -123,33 +125,39 @@ __global__ __launch_bounds__(NT) void cofold_mfe_kernel(CoArgs A) {
           const int w = Wc[dp * ld + p];
           const int cpq = w >> 8;
           if (cpq >= HALF) continue;
-          c = min(c, cpq + mfe_intloop(sm, T, u1, u2, t, si1, sj1, w & 127));
+          m = min(m, cpq + mfe_intloop(sm, T, u1, u2, t, si1, sj1, w & 127));
         }
+        int dec = INF;
         if (adj_i && adj_j) {
-          int dec = INF;
-          for (int u = i + 2; u <= j - 2; u++) {
+          for (int u = i + 2 + lane; u <= j - 2; u += WAVE) {
             if (u == cut) continue;                                   // u, u+1 must be neighbours
             const int a = FML[(u - i - 1) * ld + i + 1], b = FML[(j - u - 2) * ld + u + 1];
             if (a < HALF && b < HALF) dec = min(dec, a + b);
           }
-          if (dec < HALF) c = min(c, dec + T.MLclosing + T.MLintern + tau + sm.mmM[rtype_of(t) * 16 + sj1 * 4 + si1]);
         }
+        m = wave_min_i32(m);
+        dec = wave_min_i32(dec);
+        c = min(c, m);
+        if (dec < HALF) c = min(c, dec + T.MLclosing + T.MLintern + tau + sm.mmM[rtype_of(t) * 16 + sj1 * 4 + si1]);
         if (c >= HALF) c = INF;
         info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
       }
       const bool h5 = i > 1 && co_same(i - 1, i, cut), h3 = j < n && co_same(j, j + 1, cut);
-      Wc[d * ld + i] = c * 256 + info;
-      EXT[j * ld + i] = c < INF ? c + tau + co_endstem(sm.mmExt, sm, t, h5, sm.S[i - 1], h3, sm.S[j + 1]) : INF;
       int f = INF;
-      if (adj_i) { const int fa = FML[(d - 1) * ld + i + 1]; if (fa < HALF) f = fa + T.MLbase; }
-      if (adj_j) { const int fb = FML[(d - 1) * ld + i]; if (fb < HALF) f = min(f, fb + T.MLbase); }
-      if (c < INF) f = min(f, c + T.MLintern + tau + co_endstem(sm.mmM, sm, t, h5, sm.S[i - 1], h3, sm.S[j + 1]));
-      for (int u = i + 1; u <= j - 2; u++) {
+      for (int u = i + 1 + lane; u <= j - 2; u += WAVE) {
         if (u == cut) continue;
         const int a = FML[(u - i) * ld + i], b = FML[(j - u - 1) * ld + u + 1];
         if (a < HALF && b < HALF) f = min(f, a + b);
       }
-      FML[d * ld + i] = f;
+      f = wave_min_i32(f);
+      if (adj_i) { const int fa = FML[(d - 1) * ld + i + 1]; if (fa < HALF) f = min(f, fa + T.MLbase); }
+      if (adj_j) { const int fb = FML[(d - 1) * ld + i]; if (fb < HALF) f = min(f, fb + T.MLbase); }
+      if (c < INF) f = min(f, c + T.MLintern + tau + co_endstem(sm.mmM, sm, t, h5, sm.S[i - 1], h3, sm.S[j + 1]));
+      if (lane == 0) {
+        Wc[d * ld + i] = c * 256 + info;
+        EXT[j * ld + i] = c < INF ? c + tau + co_endstem(sm.mmExt, sm, t, h5, sm.S[i - 1], h3, sm.S[j + 1]) : INF;
+        FML[d * ld + i] = f;
+      }
     }
     __syncthreads();
     // exterior decompositions next to the nick: fcA[cut - d] of [cut-d .. cut], fcB[cut + 1 + d] of [cut+1 .. cut+1+d]
@@ -449,7 +457,8 @@ __global__ __launch_bounds__(NT) void cofold_pf_kernel(CoArgs A) {
 
   for (int d = 1; d < n; d++) {
     const int ncell = n - d;
-    for (int i = tid + 1; i <= ncell; i += NT) {
+    // one wave per cell: the lanes share the interior-loop shapes and the split points; fixed-order wave sums
+    for (int i = wave + 1; i <= ncell; i += NT / WAVE) {
       const int j = i + d;
       const bool same = co_same(i, j, cut);
       const int t = (d > TURN || !same) ? pair_type(sm.S[i], sm.S[j]) : 0;
@@ -461,7 +470,8 @@ __global__ __launch_bounds__(NT) void cofold_pf_kernel(CoArgs A) {
         const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
         if (same) qb = pf_hairpin(sm, H, i, j, t);
         else qb = sm.qA3[i + 1] * sm.qB5[j - 1] * sc2 * tau * co_pf_endstem(sm.mmExt, sm, rtype_of(t), adj_j, sj1, adj_i, si1);
-        for (int e = 0; e < NPLAN; e++) {
+        double acc = 0.0;
+        for (int e = lane; e < NPLAN; e += WAVE) {
           const int u1 = P.tb_u1[e], u2 = P.tb_u2[e];
           const int dp = d - 2 - u1 - u2;
           if (dp < 1) continue;
@@ -469,31 +479,36 @@ __global__ __launch_bounds__(NT) void cofold_pf_kernel(CoArgs A) {
           if (!co_same(i, p, cut) || !co_same(q, j, cut)) continue;
           const int fi = INFO[dp * ld + p];
           if (!fi) continue;
-          qb += QB[dp * ld + p] * co_pf_intloop(sm, T, A.scale, u1, u2, t, si1, sj1, fi);
+          acc += QB[dp * ld + p] * co_pf_intloop(sm, T, A.scale, u1, u2, t, si1, sj1, fi);
         }
+        double tmp = 0.0;
         if (adj_i && adj_j) {
-          double tmp = 0.0;
-          for (int k = i + 3; k <= j - 2; k++) {
+          for (int k = i + 3 + lane; k <= j - 2; k += WAVE) {
             if (k - 1 == cut) continue;                               // k-1, k must be neighbours
             tmp += QM[(k - i - 2) * ld + i + 1] * QM1[(j - 1 - k) * ld + k];
           }
-          qb += tmp * T.MLclosing * T.MLintern * tau * sm.mmM[rtype_of(t) * 16 + sj1 * 4 + si1] * sc2;
         }
+        acc = wave_sum_f64(acc);
+        tmp = wave_sum_f64(tmp);
+        qb += acc + tmp * T.MLclosing * T.MLintern * tau * sm.mmM[rtype_of(t) * 16 + sj1 * 4 + si1] * sc2;
         info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
       }
       const bool h5 = i > 1 && co_same(i - 1, i, cut), h3 = j < n && co_same(j, j + 1, cut);
-      QB[d * ld + i] = qb;
-      INFO[d * ld + i] = (unsigned char)info;
       double m1 = adj_j ? QM1[(d - 1) * ld + i] * b1 : 0.0;
       if (t) m1 += qb * T.MLintern * tau * co_pf_endstem(sm.mmM, sm, t, h5, sm.S[i - 1], h3, sm.S[j + 1]);
-      QM1[d * ld + i] = m1;
-      double m = m1;
-      for (int k = i + 1; k <= j - 1; k++) {
+      double m = 0.0;
+      for (int k = i + 1 + lane; k <= j - 1; k += WAVE) {
         double left = (k - 1 != cut) ? QM[(k - 1 - i) * ld + i] : 0.0;
         if (co_same(i, k, cut)) left += A.eMLb[k - i];
         m += left * QM1[(j - k) * ld + k];
       }
-      QM[d * ld + i] = m;
+      m = m1 + wave_sum_f64(m);
+      if (lane == 0) {
+        QB[d * ld + i] = qb;
+        INFO[d * ld + i] = (unsigned char)info;
+        QM1[d * ld + i] = m1;
+        QM[d * ld + i] = m;
+      }
     }
     __syncthreads();
     if (wave == 0 && cut - d >= 1) {
