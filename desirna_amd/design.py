@@ -21,7 +21,9 @@ processes (it iterates over ``set`` objects of strings, whose order depends on P
 Alternative structures: "snake" moves (connected components of the pair graph of target + alternative structures
 switch between their Watson-Crick colourings) as in the reference (:143-388, :1081-1095).
 
-Not supported here (raises): two-strand inputs, ``-nd``, ``-acgu``.
+``-acgu on`` (weighted letter choices) is available in the Python driver (``DesignProblem(acgu=...)``).
+
+Not supported here (raises): ``-nd``.
 """
 import argparse
 import random
@@ -64,7 +66,10 @@ def read_input(path):
 class DesignProblem:
     """Target structure + restraints -> per-position letter sets and pairing partners (reference get_nt_list)."""
 
-    def __init__(self, sec_struct, seq_restr=None, alt_sec_structs=None):
+    def __init__(self, sec_struct, seq_restr=None, alt_sec_structs=None, acgu=None):
+        # acgu: None (= -acgu off) or the nucleotide percentages of -acgu on, e.g. {'A': 15, 'C': 30, 'G': 30, 'U': 15}:
+        # weighted letter choices in the initial sequence and in pair moves (reference :725-741, :1052-1064)
+        self.acgu = acgu
         # two strands: the '&' stays in every string as a fixed, unpaired "letter" exactly as in the reference (its positions
         # count; seq_restr carries it too), so indices, windows and draw counts are the reference's
         self.two_strands = "&" in sec_struct
@@ -173,6 +178,11 @@ class DesignProblem:
                     s[i] = "U"
         for i, j in sorted(self.pairs):
             a, b = self.allowed[i], self.allowed[j]
+            if self.acgu is not None:
+                opts_i = sorted(a)
+                s[i] = rng.choices(opts_i, weights=[self.acgu[x] for x in opts_i])[0]
+                s[j] = WC[s[i]]
+                continue
             if "C" in a and "G" in a and "C" in b and "G" in b:
                 s[i] = rng.choice(["C", "G"]); s[j] = WC[s[i]]
             elif "C" in a and "G" in b:
@@ -253,21 +263,27 @@ class DesignProblem:
                 s[pos] = rng.choice(opts)
         else:
             opts1 = sorted(x for x in self.allowed[pos] if x != s[pos]) if len(self.allowed[pos]) != 1 else list(self.allowed[pos])
-            n1 = rng.choice(opts1)
+            if self.acgu is not None:
+                n1 = rng.choices(opts1, weights=[self.acgu[x] for x in opts1])[0]
+            else:
+                n1 = rng.choice(opts1)
             opts2 = sorted(set(self.allowed[j]) & set(CAN_PAIR[n1]))
             if opts2:
-                s[pos], s[j] = n1, rng.choice(opts2)
+                if self.acgu is not None:
+                    s[pos], s[j] = n1, rng.choices(opts2, weights=[self.acgu[x] for x in opts2])[0]
+                else:
+                    s[pos], s[j] = n1, rng.choice(opts2)
         return "".join(s)
 
 
 def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off"):
+               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off", acgu=None):
     """Replica-exchange Monte-Carlo design of one target.  Returns dict(best=ScoreSeq, solved=bool, history=..., stats=...).
 
     ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
     own replicas and all-gathers the scores before each exchange attempt."""
-    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
+    prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs, acgu=acgu)
     pks = "on" if set(input_file.sec_struct) - set(".()&") else "off"
     if prob.two_strands:
         oligo_state = "homodimer" if dimer == "on" else "heterodimer"       # reference DesiRNA.py:474-485
@@ -513,13 +529,20 @@ def main(argv=None):
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
     ap.add_argument("-d", "--dimer", default="off", choices=["off", "on"], dest="dimer", help="homodimer design (two-strand input)")
     ap.add_argument("-oa", "--avoid_oligomerization", default="off", choices=["off", "on"], dest="oligo")
+    ap.add_argument("-acgu", "--ACGU", default="off", choices=["off", "on"], dest="percs", help="weighted nucleotide choices")
+    ap.add_argument("-acgu_content", "--ACGU_content", default="", dest="acgu_content", help="A,C,G,U percentages (sum 100)")
     ap.add_argument("--python-host", action="store_true", help="per-replica Python host loop instead of the native batched one")
     ap.add_argument("-o", "--outdir", default=None, help="write the reference's result files (_results.csv, _traj.csv, "
                     "_stats, _best_str, fasta files) into this directory")
     a = ap.parse_args(argv)
     inp = read_input(a.name)
-    two = "&" in inp.sec_struct or a.oligo == "on"
+    two = "&" in inp.sec_struct or a.oligo == "on" or a.percs == "on"
     extra = dict(dimer=a.dimer, oligo=a.oligo) if two else {}
+    if a.percs == "on":
+        vals = [int(x) for x in a.acgu_content.split(",")] if a.acgu_content else [15, 30, 30, 15]
+        if sum(vals) != 100:
+            raise SystemExit("The ACGU content should sum up to 100, check your command.")
+        extra["acgu"] = dict(zip("ACGU", vals))
     res = (run_design if (a.python_host or two) else run_design_fast)(inp, **extra, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
                      t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
                      seed=a.in_seed, stop_when_solved=a.sws == "on")

@@ -144,3 +144,21 @@ def test_output_files_byte_for_byte():
     assert outputs.get_outname(c["infile"], c["replicas"], c["RE_attempt"], c["timlim"], c["pks"], c["acgu_percentages"], c["T_min"],
                                c["T_max"], c["param"], [tuple(x) for x in c["scoring_f"]], c["oligo"], c["dimer"],
                                c["point_mutations"]) == g["outname"]
+
+
+def test_acgu_weighted_choices():
+    """-acgu on: weighted letter choices (default content A15 C30 G30 U15) in the initial sequence and in pair moves."""
+    g = GOLD["acgu"]
+    d = GOLD["inputs"]["Standard_design_input"]
+    prob = design.DesignProblem(d["sec_struct"], d["seq_restr"], None, acgu=g["percentages"])
+    for c in g["initial"]:
+        rng = random.Random(c["seed"])
+        assert prob.initial_sequence(rng) == c["sequence"] and rng.random() == c["next_random"]
+    for c in g["proposals"]:
+        rng = random.Random(c["seed"])
+        pos = prob.mutation_position(c["mfe_ss"], c["shelf"], c["n_shelves"], 0.7, 0.0, True, rng)
+        mine = prob.mutate(c["sequence"], pos, rng)
+        assert rng.random() == c["next_random"]
+        j = int(prob.partner[pos])
+        if mine != c["proposed"]:                 # second letter of a pair move: the reference's list order is a set's
+            assert j >= 0 and mine[pos] == c["proposed"][pos] and mine[j] in CAN_PAIR[mine[pos]]

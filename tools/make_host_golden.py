@@ -222,6 +222,31 @@ def main():
                     "stats": {"global_step": 3, "step": 300, "acc_mc_step": 211, "acc_mc_better_e": 150, "rej_mc_step": 89,
                               "acc_re_step": 4, "rej_re_step": 5}, "finish_time": 83.4,
                     "outname_case": {k: getattr(o2, k) for k in vars(o2)}, "outname": sio.get_outname(o2)}
+    # ---- -acgu on (weighted letter choices, default content A15 C30 G30 U15): initial sequences and proposals on the
+    # standard example input
+    G["acgu"] = {"percentages": {"A": 15, "C": 30, "G": 30, "U": 15}, "initial": [], "proposals": []}
+    inp = sio.read_input(os.path.join(in_dir, "Standard_design_input.txt"))
+    inp.pairs = su.check_dot_bracket(inp.sec_struct)
+    inp.set_target_pairs_tupl()
+    nt_list = su.get_nt_list(inp)
+    temps = su.get_rep_temps(types.SimpleNamespace(replicas=10, T_min=10, T_max=150))
+    opts = types.SimpleNamespace(acgu_percentages="on", nt_percentages=G["acgu"]["percentages"], point_mutations="on", tm_max=0.7,
+                                 tm_min=0.0, rep_temps_shelfs=temps, oligo_state="none", pks="off")
+    for k in range(8):
+        random.seed(k)
+        init = su.initial_sequence_generator(nt_list, inp, opts)
+        G["acgu"]["initial"].append({"seed": k, "sequence": init, "next_random": random.random()})
+    random.seed(4242)
+    base_seq = su.initial_sequence_generator(nt_list, inp, opts)
+    for k in range(60):
+        so = es.ScoreSeq(sequence=base_seq)
+        so.get_mfe_ss("." * len(base_seq))
+        so.get_temp_shelf(temps[k % 10])
+        so.get_replica_num(1)
+        random.seed(7000 + k)
+        su.mutate_sequence(so, nt_list, opts, inp)
+        G["acgu"]["proposals"].append({"sequence": base_seq, "mfe_ss": "." * len(base_seq), "shelf": k % 10, "n_shelves": 10,
+                                       "seed": 7000 + k, "proposed": recorded["seq"], "next_random": random.random()})
     with open(out, "w") as fh:
         json.dump(G, fh, indent=0, sort_keys=True)
     print({k: (len(v) if hasattr(v, "__len__") else v) for k, v in G.items()})
