@@ -22,6 +22,7 @@
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
+#include "fold_subopt.hpp"
 #include "host_driver.hpp"
 #include "tables.hpp"
 
@@ -650,6 +651,48 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, total, hipMemcpyDeviceToHost));
   }
   if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
+
+// ---------------------------------------------------------------- second-best structure energy (-nd on)
+
+template <int NT>
+static void launch_subopt(const SubArgs& a, int R, hipStream_t s) {
+  hipLaunchKernelGGL(subopt_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+
+extern "C" int drna_subopt_energy_batch(drna_engine* e, int R, int L, const char* seqs, int32_t* E2, int32_t* E12) {
+  if (!e) return DRNA_ERR_ARG;
+  if (R < 1 || R > e->max_R || L < 1 || L > e->max_L || !seqs || !E2) {
+    e->err = "drna_subopt_energy_batch: bad argument (R, L within the engine's limits; seqs and E2 required)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
+  const int ld = L + 2;
+  for (int k = 0; k < e->max_R; k++) e->h_status[k] = ST_OK;
+  SubArgs a;
+  a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = e->d_seqs; a.L = L; a.ld = ld;
+  a.ws = reinterpret_cast<int32_t*>(e->d_ws_pf); a.ws_stride = 2 * (long long)pf_ws_stride(ld);   // int32 units of the PF workspace
+  a.E2 = e->d_Emfe; a.E12 = reinterpret_cast<int32_t*>(e->d_Epf); a.status = e->d_status;
+  HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+  if (e->nt == 256) launch_subopt<256>(a, R, e->s_mfe);
+  else if (e->nt == 512) launch_subopt<512>(a, R, e->s_mfe);
+  else launch_subopt<1024>(a, R, e->s_mfe);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+  HIP_TRY(hipStreamSynchronize(e->s_mfe));
+  HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
+  e->timing[1] = e->timing[2] = 0.f; e->timing[3] = e->timing[0];
+  for (int r = 0; r < R; r++)
+    if (e->h_status[r] == ST_BAD_CHAR) {
+      char buf[96];
+      snprintf(buf, sizeof buf, "sequence %d holds a character other than A C G U T", r);
+      e->err = buf;
+      return DRNA_ERR_SEQUENCE;
+    }
+  HIP_TRY(hipMemcpy(E2, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (E12) HIP_TRY(hipMemcpy(E12, e->d_Epf, (size_t)2 * R * sizeof(int32_t), hipMemcpyDeviceToHost));
   return DRNA_OK;
 }
 

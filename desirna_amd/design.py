@@ -278,7 +278,7 @@ class DesignProblem:
 
 def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off", acgu=None):
+               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off", acgu=None, subopt="off"):
     """Replica-exchange Monte-Carlo design of one target.  Returns dict(best=ScoreSeq, solved=bool, history=..., stats=...).
 
     ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
@@ -289,7 +289,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
         oligo_state = "homodimer" if dimer == "on" else "heterodimer"       # reference DesiRNA.py:474-485
     else:
         oligo_state = "avoid" if oligo == "on" else "none"
-    opts = SimpleNamespace(oligo_state=oligo_state, pks=pks, subopt="off", motifs=None, param="1999",
+    opts = SimpleNamespace(oligo_state=oligo_state, pks=pks, subopt=subopt, motifs=None, param="1999",
                            scoring_f=es.parse_scoring_functions(scoring_f))
     shards = shards or rx.ReplicaShards(replicas, 0, 1)
     local = shards.local
@@ -529,6 +529,7 @@ def main(argv=None):
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
     ap.add_argument("-d", "--dimer", default="off", choices=["off", "on"], dest="dimer", help="homodimer design (two-strand input)")
     ap.add_argument("-oa", "--avoid_oligomerization", default="off", choices=["off", "on"], dest="oligo")
+    ap.add_argument("-nd", "--negative_design", default="off", choices=["off", "on"], dest="subopt")
     ap.add_argument("-acgu", "--ACGU", default="off", choices=["off", "on"], dest="percs", help="weighted nucleotide choices")
     ap.add_argument("-acgu_content", "--ACGU_content", default="", dest="acgu_content", help="A,C,G,U percentages (sum 100)")
     ap.add_argument("--python-host", action="store_true", help="per-replica Python host loop instead of the native batched one")
@@ -536,8 +537,8 @@ def main(argv=None):
                     "_stats, _best_str, fasta files) into this directory")
     a = ap.parse_args(argv)
     inp = read_input(a.name)
-    two = "&" in inp.sec_struct or a.oligo == "on" or a.percs == "on"
-    extra = dict(dimer=a.dimer, oligo=a.oligo) if two else {}
+    two = "&" in inp.sec_struct or a.oligo == "on" or a.percs == "on" or a.subopt == "on"
+    extra = dict(dimer=a.dimer, oligo=a.oligo, subopt=a.subopt) if two else {}
     if a.percs == "on":
         vals = [int(x) for x in a.acgu_content.split(",")] if a.acgu_content else [15, 30, 30, 15]
         if sum(vals) != 100:

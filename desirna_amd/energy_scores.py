@@ -15,8 +15,8 @@ Two strands (``oligo_state`` heterodimer / homodimer, and ``avoid`` = ``-o on``)
 (co-fold MFE + partition function + two-strand evaluation on the GPU); the oligomer / monomer bonus terms of
 ``utils/dimer_multichain_energy.py`` are computed here from its free energies.
 
-Out of scope here: ``-nd on`` sub-optimal search -- it raises NotImplementedError rather than silently
-giving different numbers.
+``-nd on`` (negative design): the energy of the second-best structure comes from ``Engine.subopt_energy`` (two-best
+dynamic programme on the GPU; no golden in the reference: checked against exhaustive enumeration).
 """
 from . import engine as _engine
 from .sim_score import batch_metrics
@@ -138,6 +138,15 @@ class ScoreSeq:
     def get_edesired_minus_MFE(self):
         self.edesired_minus_MFE = self.edesired - self.MFE
 
+    def get_subopt_e(self, e_subopt):
+        self.subopt_e = e_subopt
+
+    def get_esubopt_minus_Epf(self, Epf, e_subopt):
+        self.esubopt_minus_Epf = e_subopt - Epf
+
+    def get_scoring_function_w_subopt(self):
+        self.scoring_function = self.scoring_function - self.esubopt_minus_Epf
+
     def get_ensemble_defect(self, ensemble_defect):
         """reference :362-374 runs mfe / rescale / pf / ensemble_defect on a new fold compound; here the value
         comes from the engine's inside + outside kernels (Engine.ensemble_defect).  The attribute is created on
@@ -185,8 +194,9 @@ class ReplicaScorer:
         self.oligo_state = getattr(sim_options, "oligo_state", "none")
         if self.oligo_state not in ("none", "avoid", "heterodimer", "homodimer"):
             raise ValueError("unknown oligo_state %r" % self.oligo_state)
-        if getattr(sim_options, "subopt", "off") == "on":
-            raise NotImplementedError("-nd on (sub-optimal search) is not part of the GPU path")
+        self.subopt = getattr(sim_options, "subopt", "off") == "on"
+        if self.subopt and self.oligo_state in ("heterodimer", "homodimer"):
+            raise NotImplementedError("-nd on with two-strand inputs")
         self.input_file = input_file
         self.sim_options = sim_options
         self.target = input_file.sec_struct.replace("&", "")
@@ -239,9 +249,16 @@ class ReplicaScorer:
                 sc.get_edesired2(sum(energies) / len(energies))
                 sc.get_edesired2_minus_Epf(sc.Epf, sc.edesired2)
                 sc.get_scoring_function_w_alt_ss()
-            if getattr(self.sim_options, "motifs", None):
-                sc.update_scoring_function_w_motifs(score_motifs(seq, self.sim_options))
             res.append(sc)
+        if self.subopt:
+            # reference :105-108 (-nd on): for solved candidates (1-MCC == 0) the energy of the first sub-optimal structure
+            hit = [k for k, sc in enumerate(res) if sc.mcc == 0]
+            if hit:
+                e2 = self.engine.subopt_energy([seqs[k] for k in hit])
+                for k, v in zip(hit, e2):
+                    res[k].get_subopt_e(int(v) / 100.0)
+                    res[k].get_esubopt_minus_Epf(res[k].Epf, res[k].subopt_e)
+                    res[k].get_scoring_function_w_subopt()
         if self.oligo_state == "avoid":
             # reference get_scoring_function_monomer (:411-418): homodimer of the sequence with itself, monomer fraction bonus
             # (applied before the motif bonus in the reference; both are additive)
@@ -250,6 +267,9 @@ class ReplicaScorer:
                 sc.oligo_fraction = float(oligo_fraction(co["FA"][k], co["FB"][k], co["FcAB"][k]))
                 sc.monomer_bonus = float(kTlog_monomer_fraction(sc.oligo_fraction))
                 sc.scoring_function = sc.scoring_function + sc.monomer_bonus
+        if getattr(self.sim_options, "motifs", None):
+            for seq, sc in zip(seqs, res):
+                sc.update_scoring_function_w_motifs(score_motifs(seq, self.sim_options))
         return res
 
     def _score_two_strands(self, seqs):

@@ -24,7 +24,7 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch")
 
 
 class EngineError(RuntimeError):
@@ -73,6 +73,8 @@ def load_library(path=None):
     L.drna_mc_run.restype = ci
     L.drna_mc_run.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, C.c_double, C.c_double, ci, vp,
                               C.c_double, ci, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.drna_subopt_energy_batch.restype = ci
+    L.drna_subopt_energy_batch.argtypes = [vp, ci, ci, C.c_char_p, vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -241,6 +243,18 @@ class Engine:
                                         p(rng_state), p(state["seqs"]), p(state["mfe_ss"]), p(state["score"]), p(state["mcc1"]),
                                         p(state["Epf"]), p(state["Ed"]), p(counters), p(best["seq"]), p(best["ss"]), p(best["vals"])))
 
+    def subopt_energy(self, seqs, want_both=False):
+        """Energy (dcal/mol) of the second-best structure of each sequence as the reference's -nd on path takes it from
+        ViennaRNA's subopt (0 if none within 49 kcal/mol); with want_both also the (R, 2) array of the two lowest energies."""
+        R, L = len(seqs), len(seqs[0])
+        if any(len(s) != L for s in seqs):
+            raise ValueError("all sequences of a batch must have the same length")
+        E2 = np.zeros(R, dtype=np.int32)
+        E12 = np.zeros((R, 2), dtype=np.int32) if want_both else None
+        self._check(self._L.drna_subopt_energy_batch(self._h, R, L, "".join(seqs).encode("ascii"), E2.ctypes.data,
+                                                     E12.ctypes.data if want_both else None))
+        return (E2, E12) if want_both else E2
+
     def ensemble_defect(self, seqs, want_bpp=False):
         """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
         utils/energy_scores.py:362-374).  Returns float64[R]; with want_bpp also the (R, L+1, L+1) base-pair
@@ -363,5 +377,5 @@ class HostKernels:
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
             raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch")
         return acc.astype(bool), bet.astype(bool)

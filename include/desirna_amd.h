@@ -122,6 +122,15 @@ int drna_cofold_batch(drna_engine *e, int R, int L, int cut, const char *seqs, u
                       int32_t *Emfe, char *mfe_ss, int32_t *Ed);
 
 /*
+ * Energy of the second-best structure of R sequences (negative design, -nd on).  Replaces
+ * get_first_suboptimal_structure_and_energy(seq, fc, 1)[1] (utils/energy_scores.py:105-107, :453-488): ViennaRNA's subopt
+ * enumeration with a growing energy band until it holds two structures, sorted by energy, second entry.
+ *   E2   R int32, dcal/mol; 0 when no second structure lies within 4900 dcal/mol of the MFE (the reference's fallback)
+ *   E12  R*2 int32, may be NULL: the two lowest structure energies (second = 10000000 if there is one structure only)
+ */
+int drna_subopt_energy_batch(drna_engine *e, int R, int L, const char *seqs, int32_t *E2, int32_t *E12);
+
+/*
  * Ensemble defect of R sequences against targets[0] (needs drna_set_targets with the same L): inside fill,
  * outside recursion, base-pair probabilities, then (1/L) * [ sum_{i unpaired in target} sum_j P(i,j)
  * + sum_{i paired with m in target} (1 - P(i,m)) ], '(' ')' pairs only.

@@ -1459,3 +1459,110 @@ void orc_cofold_pf(const orc_params *P, const char *seq, int n, int cut, double 
   out[3] = -kT * (log(Qtot) + n * lsc);
   free(S); free(up); free(qb); free(qm); free(qm1); free(q5); free(qA3); free(qB5); free(scale); free(eMLb);
 }
+
+/* ---------------------------------------------------------------- second-best structure
+ *
+ * get_first_suboptimal_structure_and_energy(seq, fc, 1)[1] of reference utils/energy_scores.py:453-488: ViennaRNA's
+ * subopt (Wuchty et al. 1999, uniq_ML = 1: every structure once) is run with a growing energy band (1, 2, ... 49 kcal/mol)
+ * until it returns at least two structures; they are sorted by energy and the second one is taken.  What the caller
+ * uses is that structure's ENERGY = the lowest energy over all structures other than one minimum-energy structure
+ * (equal to the MFE if the ground state is degenerate); 0.0 if no second structure lies within 49 kcal/mol.
+ *
+ * Restated as a two-best dynamic programme over an UNAMBIGUOUS decomposition (each structure has exactly one
+ * derivation, so the two smallest values of a table entry belong to two different structures):
+ *   F[j]    = { F[j-1] ; F[i-1] + C[i,j] + ext(i,j) }
+ *   C[i,j]  = { hairpin ; C[p,q] + interior ; M2[i+1,j-1] + closing }
+ *   M[i,j]  (>= 1 stem) = { M[i,j-1] + b ; (k-i) b + C[k,j] + stem ; M[i,k-1] + C[k,j] + stem }
+ *   M2[i,j] (>= 2 stems) = { M2[i,j-1] + b ; M[i,k-1] + C[k,j] + stem }
+ * NOT pinned by the reference (no golden for -nd on); checked against exhaustive enumeration on short sequences. */
+typedef struct { int a, b; } top2;
+static inline top2 t2_new(void) { top2 t = {INF, INF}; return t; }
+static inline void t2_add(top2 *t, int v) {
+  if (v >= INF / 2) return;
+  if (v < t->a) { t->b = t->a; t->a = v; }
+  else if (v < t->b) t->b = v;
+}
+static inline void t2_add_sum(top2 *t, top2 x, int e) {       /* x + e */
+  if (x.a < INF / 2) t2_add(t, x.a + e);
+  if (x.b < INF / 2) t2_add(t, x.b + e);
+}
+static inline void t2_add_sum2(top2 *t, top2 x, top2 y, int e) { /* x + y + e: the three best combinations */
+  if (x.a >= INF / 2 || y.a >= INF / 2) return;
+  t2_add(t, x.a + y.a + e);
+  if (y.b < INF / 2) t2_add(t, x.a + y.b + e);
+  if (x.b < INF / 2) t2_add(t, x.b + y.a + e);
+}
+
+/* returns 1 and the two lowest energies (dcal/mol) in e[0] <= e[1]; e[1] = INF when there is only one structure */
+int orc_two_best(const orc_params *P, const char *seq, int n, int e[2]) {
+  const int W = n + 2;
+  size_t W2 = (size_t)W * (size_t)W;
+  int *S = encode_seq(seq, n);
+  char *up = (char *)malloc((size_t)n + 1);
+  for (int i = 0; i < n; i++) {
+    char ch = seq[i];
+    ch = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch;
+    up[i] = (ch == 'T') ? 'U' : ch;
+  }
+  up[n] = 0;
+  top2 *C = (top2 *)malloc(W2 * sizeof(top2)), *M = (top2 *)malloc(W2 * sizeof(top2)), *M2 = (top2 *)malloc(W2 * sizeof(top2));
+  top2 *F = (top2 *)malloc(sizeof(top2) * (size_t)(n + 2));
+  for (size_t k = 0; k < W2; k++) { C[k] = t2_new(); M[k] = t2_new(); M2[k] = t2_new(); }
+  for (int d = TURN + 1; d < n; d++)
+    for (int i = 1; i + d <= n; i++) {
+      int j = i + d;
+      int t = PAIR[S[i]][S[j]];
+      top2 c = t2_new();
+      if (t) {
+        t2_add(&c, E_Hairpin(P, j - i - 1, t, S[i + 1], S[j - 1], up + i - 1));
+        for (int p = i + 1; p <= MIN2(j - 2 - TURN, i + MAXLOOP + 1); p++)
+          for (int q = j - 1; q >= p + TURN + 1; q--) {
+            if (p - i - 1 + j - q - 1 > MAXLOOP) break;
+            int t2 = PAIR[S[p]][S[q]];
+            if (!t2) continue;
+            t2_add_sum(&c, C[IDX(p, q)], E_IntLoop(P, p - i - 1, j - q - 1, t, RTYPE[t2], S[i + 1], S[j - 1], S[p - 1], S[q + 1]));
+          }
+        t2_add_sum(&c, M2[IDX(i + 1, j - 1)], P->MLclosing + E_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]));
+      }
+      C[IDX(i, j)] = c;
+      top2 m = t2_new(), m2 = t2_new();
+      t2_add_sum(&m, M[IDX(i, j - 1)], P->MLbase);
+      t2_add_sum(&m2, M2[IDX(i, j - 1)], P->MLbase);
+      for (int k = i; k <= j - TURN - 1; k++) {
+        int tk = PAIR[S[k]][S[j]];
+        if (!tk) continue;
+        top2 ck = C[IDX(k, j)];
+        if (ck.a >= INF / 2) continue;
+        int st = E_MLstem(P, tk, S[k - 1], S[j + 1]);
+        t2_add_sum(&m, ck, (k - i) * P->MLbase + st);
+        if (k - 1 >= i) {
+          t2_add_sum2(&m, M[IDX(i, k - 1)], ck, st);
+          t2_add_sum2(&m2, M[IDX(i, k - 1)], ck, st);
+        }
+      }
+      M[IDX(i, j)] = m;
+      M2[IDX(i, j)] = m2;
+    }
+  F[0] = t2_new(); F[0].a = 0;
+  for (int j = 1; j <= n; j++) {
+    top2 f = t2_new();
+    t2_add_sum(&f, F[j - 1], 0);
+    for (int i = j - TURN - 1; i >= 1; i--) {
+      int t = PAIR[S[i]][S[j]];
+      if (!t || C[IDX(i, j)].a >= INF / 2) continue;
+      t2_add_sum2(&f, F[i - 1], C[IDX(i, j)], E_ExtLoop(P, t, i > 1 ? S[i - 1] : -1, j < n ? S[j + 1] : -1));
+    }
+    F[j] = f;
+  }
+  e[0] = F[n].a; e[1] = F[n].b;
+  free(S); free(up); free(C); free(M); free(M2); free(F);
+  return 1;
+}
+
+/* the reference's number: energy (dcal/mol) of subopt_list[1]; 0 when no second structure lies within 4900 dcal/mol */
+int orc_subopt_energy(const orc_params *P, const char *seq, int n) {
+  int e[2];
+  orc_two_best(P, seq, n, e);
+  if (e[1] >= INF / 2 || e[1] - e[0] > 4900) return 0;
+  return e[1];
+}

@@ -72,6 +72,11 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
 int orc_cofold_mfe(const orc_params *P, const char *seq, int n, int cut, char *ss);
 void orc_cofold_pf(const orc_params *P, const char *seq, int n, int cut, double out[4]);
 
+/* the two lowest structure energies (dcal/mol; e[1] = 10000000 if there is one structure only) and the number the reference
+ * takes from ViennaRNA's subopt for -nd on: energy of the second entry of the sorted list (0 beyond 49 kcal/mol) */
+int orc_two_best(const orc_params *P, const char *seq, int n, int e[2]);
+int orc_subopt_energy(const orc_params *P, const char *seq, int n);
+
 /* table dumps for kernel-level parity tests: c / fML as (n+2)*(n+2) row-major int32 */
 int orc_mfe_tables(const orc_params *P, const char *seq, int n, const unsigned char *nopair,
                    int32_t *c, int32_t *fML, int32_t *f5);

@@ -124,6 +124,18 @@ class Oracle:
         self._L.orc_cofold_pf(self._P, s.encode(), len(s), len(a), out)
         return tuple(out)
 
+    def two_best(self, seq):
+        """the two lowest structure energies in dcal/mol (second = 10000000 if there is only one structure)"""
+        e = (C.c_int * 2)()
+        self._L.orc_two_best.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+        self._L.orc_two_best(self._P, seq.encode(), len(seq), e)
+        return e[0], e[1]
+
+    def subopt_energy(self, seq):
+        self._L.orc_subopt_energy.restype = C.c_int
+        self._L.orc_subopt_energy.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        return self._L.orc_subopt_energy(self._P, seq.encode(), len(seq))
+
     def simscore(self, ref, query):
         out = (C.c_double * 3)()
         conf = (C.c_int * 4)()

@@ -23,6 +23,7 @@ def build():
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
+    L.emu_subopt.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp, vp]
     L.emu_edef.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, ci, vp, vp, vp]
     return L
 
@@ -138,3 +139,14 @@ class Emu:
         assert rc == 0
         strs = [bytes(r[:cut]).decode() + "&" + bytes(r[cut:]).decode() for r in ss]
         return E, strs, F4, st, Ed
+
+    def subopt(self, seqs, nt=128):
+        """second-best structure energies: (E2 as the reference takes it, the two lowest energies)"""
+        R, L = len(seqs), len(seqs[0])
+        E2 = np.zeros(R, dtype=np.int32)
+        E12 = np.zeros((R, 2), dtype=np.int32)
+        st = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_subopt(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), nt, E2.ctypes.data,
+                               E12.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        return E2, E12, st

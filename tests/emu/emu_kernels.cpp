@@ -13,6 +13,7 @@ emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
 #include "../../desirna_amd/csrc/fold_outside.hpp"
 #include "../../desirna_amd/csrc/fold_cofold.hpp"
+#include "../../desirna_amd/csrc/fold_subopt.hpp"
 
 using namespace drna;
 
@@ -194,6 +195,24 @@ int emu_cofold(const int32_t* blob, int n_int32, int R, int L, int cut, const ch
     v.T = &c->H.mfe; v.hp_len = c->H.hp_len.data(); v.bulge_len = c->H.bulge_len.data(); v.int_len = c->H.int_len.data();
     v.seqs = seqs; v.pt = pt; v.L = L; v.n_targets = 1; v.Ed = Ed; v.cut = cut; v.DuplexInit = c->H.DuplexInit;
     for (int b = 0; b < R; b++) emu_launch(b, 64, [&]() { eval_kernel(v); });
+  }
+  delete c;
+  return 0;
+}
+
+// two-best energies (second-best structure) of R sequences
+int emu_subopt(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int nt, int32_t* E2, int32_t* E12, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  std::vector<int32_t> ws((size_t)6 * ld * ld, 0);
+  for (int r = 0; r < R; r++) {
+    SubArgs a;
+    a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data(); a.seqs = seqs; a.L = L; a.ld = ld;
+    a.ws = ws.data() - (size_t)r * 6 * ld * ld; a.ws_stride = (long long)6 * ld * ld;
+    a.E2 = E2; a.E12 = E12; a.status = status;
+    if (nt == 64) emu_launch(r, 64, [&]() { subopt_kernel<64>(a); });
+    else emu_launch(r, 128, [&]() { subopt_kernel<128>(a); });
   }
   delete c;
   return 0;

@@ -373,3 +373,38 @@ def test_two_strand_scorer_and_design_run(eng400, oracle, traj_golden, example_i
     res = design.run_design(inp, replicas=8, exchange=20, steps=3, seed=4)
     b = res["best"]
     assert b.sequence.count("&") == 1 and len(b.sequence) == len(inp.sec_struct) and b.mfe_ss.index("&") == inp.sec_struct.index("&")
+
+
+# ---- second-best structure energy (-nd on): no golden in the reference ("parity unpinned"), the oracle's
+# two-best dynamic programme is checked against exhaustive enumeration in tests/test_oracle_golden.py
+
+def test_subopt_energy_vs_oracle(eng400, oracle):
+    rng = np.random.default_rng(77)
+    for L in (5, 13, 36, 100, 200, 260):
+        seqs = [_rand(rng, L) for _ in range(4)] + [_rand(rng, L, "GC"), "A" * L]
+        E2, E12 = eng400.subopt_energy(seqs, want_both=True)
+        for k, s in enumerate(seqs):
+            assert tuple(int(x) for x in E12[k]) == oracle.two_best(s), s
+            assert int(E2[k]) == oracle.subopt_energy(s), s
+            assert int(E12[k, 0]) == oracle.mfe(s)[1]
+
+
+def test_negative_design_scoring(eng400, oracle, traj_golden, example_inputs):
+    """-nd on through ReplicaScorer (reference energy_scores.py:105-108): for candidates whose MFE structure is the target
+    the scoring function loses (E_subopt - Epf)."""
+    from types import SimpleNamespace
+    from desirna_amd.energy_scores import ReplicaScorer
+    tg = example_inputs["Standard_design_input"]["sec_struct"][0]
+    rows = [r for r in traj_golden if r["run"] == "Standard_design_input"]
+    solved = [r["sequence"] for r in rows if float(r["one_minus_mcc"]) == 0.0][:6]
+    other = [r["sequence"] for r in rows if float(r["one_minus_mcc"]) > 0.0][:3]
+    inp = SimpleNamespace(sec_struct=tg, alt_sec_struct=None, alt_sec_structs=None)
+    opts = SimpleNamespace(oligo_state="none", subopt="on", pks="off", scoring_f=[("Ed-Epf", 1.0)], motifs={}, param="1999")
+    res = ReplicaScorer(inp, opts, max_replicas=16, engine=eng400).score(solved + other)
+    for s, sc in zip(solved + other, res):
+        if sc.mcc == 0:
+            assert sc.subopt_e == oracle.subopt_energy(s) / 100.0
+            assert abs(sc.scoring_function - (sc.edesired_minus_Epf - (sc.subopt_e - sc.Epf))) < 1e-9
+        else:
+            assert sc.subopt_e == 0 and sc.scoring_function == sc.edesired_minus_Epf
+    assert sum(sc.mcc == 0 for sc in res) == len(solved)

@@ -182,3 +182,15 @@ def test_cofold_reduces_to_monomers_when_strands_cannot_interact(oracle):
     assert abs(fab - (fa + fb)) < 1e-9 and fcab == 999.0
     ss, e = oracle.cofold_mfe(a + "&" + b)
     assert ss == "." * len(a) + "&" + "." * len(b) and e == 0
+
+
+def test_two_best_against_enumeration(oracle):
+    """-nd on takes the energy of the second entry of ViennaRNA's sorted subopt list; the reference holds no golden for it
+    ("parity unpinned"): the oracle's two-best dynamic programme is checked against explicit enumeration of all structures."""
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        L = int(rng.integers(8, 16))
+        s = "".join(rng.choice(list("ACGU" if trial % 3 else "GC"), L))
+        en = sorted(oracle.eval_structure(s, st) for st in _enumerate(s, oracle))
+        assert oracle.two_best(s) == (en[0], en[1] if len(en) > 1 else 10000000), s
+    assert oracle.subopt_energy("AAAAAAAA") == 0                       # one structure only: the reference's fallback
