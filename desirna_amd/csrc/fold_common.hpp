@@ -88,6 +88,11 @@ __device__ __forceinline__ double buf_load_f64(RS rsrc, int voff, int soff) {
   return __hiloint2double((int)v[1], (int)v[0]);
 }
 
+template <typename RS>
+__device__ __forceinline__ int buf_load_i32(RS rsrc, int voff, int soff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0);
+}
+
 struct f64x2 { double x, y; };
 template <typename RS>
 __device__ __forceinline__ f64x2 buf_load_f64x2(RS rsrc, int voff, int soff) {

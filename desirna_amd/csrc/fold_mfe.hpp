@@ -174,6 +174,7 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
   }
   if (wave == 0 && TURN + 1 < n) mfe_build_plist(sm, TURN + 1, n, lane);
   __syncthreads();
+  const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)((long long)ld * ld * 4), 0x00020000);
 
   for (int d = TURN + 1; d < n; d++) {
     const int ncell = n - d, par = d & 1;
@@ -238,10 +239,27 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
         const int b = it / H, h = it - b * H;
         const int i0 = b * WAVE + lane + 1;
         const int i = i0 <= ncell ? i0 : ncell;
-        int accK = INF;
-        for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
-          accK = min(accK, FML[tt * ld + i] + FML[(d - tt - 1) * ld + i + tt + 1]);
-        sm.partK[it * WAVE + lane] = accK;
+        // fML[i,i+tt] at (tt ld + i) 4, fML[i+tt+1,j] at ((d-tt-1) ld + i+tt+1) 4 bytes from FML; a step of H in tt moves them
+        // by +4 H ld and -4 H (ld - 1): buffer loads with one running 32-bit offset each and the strides in SGPRs
+        int acc0 = INF, acc1 = INF;
+        int tt = TURN + 1 + h;
+        const int stepA = 4 * H * ld, stepC = 4 * H * (ld - 1);
+        int vA = (tt * ld + i) * 4;
+        int vC = ((d - tt - 1) * ld + i + tt + 1) * 4;                                     // operand of tt (never negative)
+        for (; tt + 3 * H <= d - TURN - 2; tt += 4 * H) {
+          const int vCl = vC - 3 * stepC;                                                   // operand of tt + 3 H: in range here
+          const int a0 = buf_load_i32(rsF, vA, 0), c0 = buf_load_i32(rsF, vCl, 3 * stepC);
+          const int a1 = buf_load_i32(rsF, vA, stepA), c1 = buf_load_i32(rsF, vCl, 2 * stepC);
+          const int a2 = buf_load_i32(rsF, vA, 2 * stepA), c2 = buf_load_i32(rsF, vCl, stepC);
+          const int a3 = buf_load_i32(rsF, vA, 3 * stepA), c3 = buf_load_i32(rsF, vCl, 0);
+          vA += 4 * stepA; vC -= 4 * stepC;
+          acc0 = min(acc0, min(a0 + c0, a2 + c2)); acc1 = min(acc1, min(a1 + c1, a3 + c3));
+        }
+        for (; tt <= d - TURN - 2; tt += H) {
+          acc0 = min(acc0, buf_load_i32(rsF, vA, 0) + buf_load_i32(rsF, vC, 0));
+          vA += stepA; vC -= stepC;
+        }
+        sm.partK[it * WAVE + lane] = min(acc0, acc1);
       }
     }
     __syncthreads();

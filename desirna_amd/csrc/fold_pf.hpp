@@ -156,6 +156,8 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   const double sc2 = A.scale[2];
   if (wave == 0 && TURN + 1 < n) pf_build_plist(sm, TURN + 1, n, lane);
   __syncthreads();
+  // QM and QM1 (adjacent tables) through one buffer descriptor
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
 
   for (int d = TURN + 1; d < n; d++) {
     const int ncell = n - d, par = d & 1;
@@ -218,10 +220,27 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
         const int b = it / H, h = it - b * H;
         const int i0 = b * WAVE + lane + 1;
         const int i = i0 <= ncell ? i0 : ncell;
-        double accK = 0.0;
-        for (int tt = TURN + 1 + h; tt <= d - TURN - 2; tt += H)
-          accK += QM[tt * ld + i] * QM1[(d - tt - 1) * ld + i + tt + 1];
-        sm.partK[it * WAVE + lane] = accK;
+        // qm[i,i+tt] at (tt ld + i) 8, qm1[i+tt+1,j] at (tab + (d-tt-1) ld + i+tt+1) 8 bytes from QM; a step of H in tt moves
+        // them by +8 H ld and -8 H (ld - 1): buffer loads with one running 32-bit offset each and the strides in SGPRs
+        double acc0 = 0.0, acc1 = 0.0;
+        int tt = TURN + 1 + h;
+        const int stepA = 8 * H * ld, stepC = 8 * H * (ld - 1);
+        int vA = (tt * ld + i) * 8;
+        int vC = (int)tab * 8 + ((d - tt - 1) * ld + i + tt + 1) * 8;                      // operand of tt (never negative)
+        for (; tt + 3 * H <= d - TURN - 2; tt += 4 * H) {
+          const int vCl = vC - 3 * stepC;                                                   // operand of tt + 3 H: in range here
+          const double a0 = buf_load_f64(rsQ, vA, 0), c0 = buf_load_f64(rsQ, vCl, 3 * stepC);
+          const double a1 = buf_load_f64(rsQ, vA, stepA), c1 = buf_load_f64(rsQ, vCl, 2 * stepC);
+          const double a2 = buf_load_f64(rsQ, vA, 2 * stepA), c2 = buf_load_f64(rsQ, vCl, stepC);
+          const double a3 = buf_load_f64(rsQ, vA, 3 * stepA), c3 = buf_load_f64(rsQ, vCl, 0);
+          vA += 4 * stepA; vC -= 4 * stepC;
+          acc0 += a0 * c0; acc1 += a1 * c1; acc0 += a2 * c2; acc1 += a3 * c3;
+        }
+        for (; tt <= d - TURN - 2; tt += H) {
+          acc0 += buf_load_f64(rsQ, vA, 0) * buf_load_f64(rsQ, vC, 0);
+          vA += stepA; vC -= stepC;
+        }
+        sm.partK[it * WAVE + lane] = acc0 + acc1;
       }
     }
     __syncthreads();

@@ -288,9 +288,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
     // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
     // not depend on which wave takes it.
-    // K items per 32-cell block: 4 once a single block is left (the operand offsets of the wider stride stay inside the
-    // descriptor only for ld >= 48)
-    const int kssh = (ncell <= 32 && ld >= 48) ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
+    // K items per 32-cell block: 4 once a single block is left
+    const int kssh = ncell <= 32 ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
     const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
     const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + PEC - 1) / PEC,
               nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
@@ -315,18 +314,19 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
         // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
         int vA = (tt * ld + i) * 8;
-        int vC = (int)tab * 8 + ((d - tt - 1 - 3 * KG) * ld + i + tt + 1 + 3 * KG) * 8;          // operand of tt + 3 KG
+        int vC = (int)tab * 8 + ((d - tt - 1) * ld + i + tt + 1) * 8;          // operand of tt (never negative)
         for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
-          const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vC, 2 * cstep);
-          const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vC, cstep);
-          const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vC, 0);
+          const int vCl = vC - 3 * cstep;                                       // operand of tt + 3 KG: in range here
+          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vCl, 3 * cstep);
+          const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vCl, 2 * cstep);
+          const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vCl, cstep);
+          const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vCl, 0);
           vA += 4 * astep; vC -= 4 * cstep;
           p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
           p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
         }
         for (; tt <= d - TURN - 2; tt += KG) {
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 3 * cstep);
+          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 0);
           p0 += a0.x * c0.x; q0 += a0.y * c0.y;
           vA += astep; vC -= cstep;
         }

@@ -94,6 +94,9 @@ static inline emu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, in
 static inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(emu_rsrc r, int voff, int soff, int) {
   emu_u32x2 o; std::memcpy(o.v, r.p + voff + soff, 8); return o;
 }
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(emu_rsrc r, int voff, int soff, int) {
+  unsigned o; std::memcpy(&o, r.p + voff + soff, 4); return o;
+}
 struct emu_u32x4 { unsigned v[4]; unsigned operator[](int k) const { return v[k]; } };
 static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_rsrc r, int voff, int soff, int) {
   emu_u32x4 o; std::memcpy(o.v, r.p + voff + soff, 16); return o;
