@@ -20,7 +20,6 @@
 namespace drna {
 
 constexpr int PF_FAST_NMAX = 200;
-constexpr int PEC = 3;          // pairable cells per bulge / 1xn work item
 constexpr int PGSLOTS = 10;       // tower entries per pinned wave: 28 residues over 3 waves
 constexpr int PNG = 3;            // sweep waves pinned to one 64-tower block
 
@@ -45,7 +44,8 @@ struct PfFastSmem {
   double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
-  double eWb[WAVE], eWo[WAVE];    // bulge / 1xn size weights of the shape each lane owns in the E items
+  double eW[128];                 // E items: size weight (x scale) of shape slot x (0..63 bulges, 64..127 1xn loops; padding 0)
+  int eshape[128];                // s = u1+u2 | u1 << 8 of the slot
   double xc[8];                   // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items)
   double tw_as[32], tw_W[32];     // by total size s of a generic loop: asymmetry-independent factors (see pf_prepare_tables)
   double tw_d[2][32][3];          // per residue: asymmetry factor, keep factor (0 forgets the previous tenant), size factor
@@ -53,7 +53,7 @@ struct PfFastSmem {
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int qhead[2];                   // work-queue head of the diagonal's floating items
-  unsigned char info[32 * RS];
+  unsigned char info[33 * RS];    // row 32 stays zero, like qbi's
   unsigned char S[PF_FAST_NMAX + 4];
   int flag;
 };
@@ -183,12 +183,26 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
-  if (tid < WAVE) {
-    // E items: lane l owns bulge (0,u) u = l+2 (l < 29) or (u,0) u = l-27 (l < 58), and 1xn loop (1,u) u = l+3 (l < 27) or
-    // (u,1) u = l-24 (l < 54); idle lanes keep a finite weight (their terms are switched off in the sweep)
-    const int bs = tid >= 58 ? 2 : tid < 29 ? tid + 2 : tid - 27, os = tid >= 54 ? 4 : tid < 27 ? tid + 4 : tid - 23;
-    sm.eWb[tid] = T.bulge[bs] * A.scale[bs + 2];
-    sm.eWo[tid] = T.interior[os] * T.eninio[os - 2] * A.scale[os + 2];
+  for (int x = tid; x < 128; x += NT) {
+    // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l: slots < 64
+    // bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3; y < 54:
+    // (u,1) u = y-24); the remaining slots are padding with weight 0
+    int s_, u1_;
+    double W = 0.0;
+    if (x < 64) {
+      const bool on = x < 58;
+      u1_ = (x < 29 || !on) ? 0 : x - 27;
+      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
+      if (on) W = T.bulge[s_] * A.scale[s_ + 2];
+    } else {
+      const int y = x - 64;
+      const bool on = y < 54;
+      u1_ = (y < 27 || !on) ? 1 : y - 24;
+      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
+      if (on) W = T.interior[s_] * T.eninio[s_ - 2] * A.scale[s_ + 2];
+    }
+    sm.eshape[x] = s_ | (u1_ << 8);
+    sm.eW[x] = W;
   }
   if (tid == 0) {
     sm.xc[0] = T.bulge[1] * A.scale[3]; sm.xc[1] = T.interior[5] * T.eninio[1] * A.scale[7];
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     sm.tw_W[k] = k >= 6 && k <= 30 ? T.interior[k] * A.scale[k + 2] : 0.0;
   }
   for (int k = tid; k < 4 * RS; k += NT) sm.dring[k] = 0.0;
-  for (int k = tid; k < RS; k += NT) sm.qbi[32 * RS + k] = 0.0;
+  for (int k = tid; k < RS; k += NT) { sm.qbi[32 * RS + k] = 0.0; sm.info[32 * RS + k] = 0; }
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * PNG * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
@@ -266,11 +280,6 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   long long st_last = clock64();
   long long* dbg = reinterpret_cast<long long*>(base + 5 * tab);     // the U table is unused by this kernel
 #endif
-  // E: loop shapes of this lane.  pass 0: bulges, lanes 0..28 (0,u) u = lane+2, lanes 29..57 (u,0) u = lane-27;
-  // pass 1: 1 x n loops, lanes 0..26 (1,u) u = lane+3, lanes 27..53 (u,1) u = lane-24
-  const bool b_on = lane < 58, o_on = lane < 54;
-  const int b_u1 = (lane < 29 || !b_on) ? 0 : lane - 27, b_s = !b_on ? 2 : lane < 29 ? lane + 2 : lane - 27;
-  const int o_u1 = (lane < 27 || !o_on) ? 1 : lane - 24, o_s = !o_on ? 4 : lane < 27 ? lane + 4 : lane - 23;     // s = u1 + u2
   // X: weights of the nine fixed shapes (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2) (2,3) (3,2)
 
   // QM and QM1 (adjacent tables) through one buffer descriptor
@@ -291,11 +300,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // K items per 32-cell block: 4 once a single block is left
     const int kssh = ncell <= 32 ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
     const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
-    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + PEC - 1) / PEC,
+    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2,
               nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
-    const int b_dp = d - 2 - b_s, o_dp = d - 2 - o_s;
-    const bool b_ok = b_on && b_dp > TURN, o_ok = o_on && o_dp > TURN;
-    const int b_off = (b_dp & 31) * RS + 1 + b_u1, o_off = (o_dp & 31) * RS + 1 + o_u1;
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
     for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
       if (it < nK) {
@@ -347,47 +353,39 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
         }
       } else if (it < nK + nE) {
-        // PEC pairable cells per item, all loads of a stage issued before the first is consumed
-        const int q = PEC * (it - nK);
-        int i0[PEC], ij[PEC];
+        // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots (two staged halves:
+        // bulges, then 1xn loops; shapes whose inner pair would be too short read the zero row), the row sum takes four DPP
+        // steps for all four cells at once, lane 15 of each row is the only writer
+        const int q = 4 * (it - nK) + (lane >> 4);
+        const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
+        const int i0 = pe & 255, ij = pe >> 8;
+        double acc[2];
 #pragma unroll
-        for (int c = 0; c < PEC; c++) {
-          const int pe = sm.plist[par][as_vector(q + c < pcnt ? q + c : q)];
-          i0[c] = pe & 255; ij[c] = pe >> 8;
+        for (int half = 0; half < 2; half++) {
+          int sh[4], off[4], f[4];
+          double w[4], rr[4], ww[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { sh[k] = sm.eshape[half * 64 + k * 16 + (lane & 15)]; ww[k] = sm.eW[half * 64 + k * 16 + (lane & 15)]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int dp = d - 2 - (sh[k] & 255);                // diagonal of the inner pair
+            off[k] = (dp > TURN ? (dp & 31) * RS + 1 + (sh[k] >> 8) : 32 * RS) + i0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) { w[k] = sm.qbi[off[k]]; f[k] = sm.info[off[k]]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) rr[k] = half ? sm.r1n[f[k]] : sm.rbul[f[k]];
+          double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) a += w[k] * rr[k] * ww[k];
+          acc[half] = a;
         }
-        const double b_W = sm.eWb[lane], o_W = sm.eWo[lane];
-        double wb[PEC], wo[PEC];
-        int fb[PEC], fo[PEC];
-#pragma unroll
-        for (int c = 0; c < PEC; c++) {
-          wb[c] = sm.qbi[b_off + i0[c]]; wo[c] = sm.qbi[o_off + i0[c]];
-          fb[c] = sm.info[b_off + i0[c]]; fo[c] = sm.info[o_off + i0[c]];
-        }
-        double rb[PEC], ro[PEC], mo[PEC];
-#pragma unroll
-        for (int c = 0; c < PEC; c++) { rb[c] = sm.rbul[fb[c]]; ro[c] = sm.r1n[fo[c]]; mo[c] = sm.mm1n[ij[c]]; }
-        double v[PEC];
-#pragma unroll
-        for (int c = 0; c < PEC; c++)
-          v[c] = (b_ok ? wb[c] * rb[c] * b_W : 0.0) * ((ij[c] >> 4) > 2 ? eTau : 1.0) + (o_ok ? wo[c] * ro[c] * o_W : 0.0) * mo[c];
-        // PEC interleaved wave sums (lane 63 ends with the totals)
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x111, 0xF>(v[c]);
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x112, 0xF>(v[c]);
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x114, 0xF>(v[c]);
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x118, 0xF>(v[c]);
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x142, 0xA>(v[c]);
-#pragma unroll
-        for (int c = 0; c < PEC; c++) v[c] = dpp_add_f64<0x143, 0xC>(v[c]);
-        if (lane == WAVE - 1) {
-#pragma unroll
-          for (int c = 0; c < PEC; c++)
-            if (q + c < pcnt) sm.accE[par][i0[c] + slot0] = v[c];
-        }
+        double v = acc[0] * ((ij >> 4) > 2 ? eTau : 1.0) + acc[1] * sm.mm1n[ij];
+        v = dpp_add_f64<0x111, 0xF>(v);
+        v = dpp_add_f64<0x112, 0xF>(v);
+        v = dpp_add_f64<0x114, 0xF>(v);
+        v = dpp_add_f64<0x118, 0xF>(v);
+        if ((lane & 15) == 15 && q < pcnt) sm.accE[par][i0 + slot0] = v;
       } else {
         const int xi = it - nK - nE;
         const int ch = xi / 3, grp = xi - 3 * ch;
