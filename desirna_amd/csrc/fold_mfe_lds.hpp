@@ -39,9 +39,13 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int rowoff[MFE_FAST_NMAX + 2]; // offset of row d in fml[]
   int accG[2][NSLOT], accI[2][NSLOT], accK[2][NSLOT];   // per-tower minima, double-buffered by diagonal parity (ds_min)
   // tables with the inner pair's terminal-AU term taken out (it is folded into wring)
-  int stackp[64], int11p[1024], mm1np[128], mm23p[128];
+  // one array, so that a shape slot can pick its table by offset: stack (XT_STACK), 1x1 (XT_INT11), 1xn mismatch
+  // (XT_MM1N), 2x3 mismatch (XT_MM23)
+  static constexpr int XT_STACK = 0, XT_INT11 = 64, XT_MM1N = 64 + 1024, XT_MM23 = 64 + 1024 + 128;
+  int xtab[64 + 1024 + 128 + 128];
   // per-diagonal tables prepared one step ahead by the finalize waves (double-buffered by diagonal parity)
-  int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8
+  int plist[2][NL];              // pairable cells of the diagonal: i | ij << 8 | e(2x2 loop) << 15
+  int xe[2][NL];                 // their 1x2 / 2x1 loop energies (two signed halves), inner TermAU taken out
   int pcnt[2];
   int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
   int eshape[128];               // bulge / 1xn shape slots of the E items: s = u1+u2 | u1 << 8 | size term << 16
@@ -178,7 +182,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   const int NG = NA / NB;                  // sweep waves pinned to one tower block (>= 3 for n <= 256, NT = 1024)
   const int my_tb = aw >= 0 ? aw / NG : NB, my_g = aw >= 0 ? aw - my_tb * NG : 0;
   const bool pinned = aw >= 0 && my_tb < NB;
-  const int w_tab = NB > 1 ? 1 : 0, w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
+  // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
+  const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;
 
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
@@ -189,13 +194,16 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   for (int x = tid; x < 128; x += NT) {
     // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l:
     // slots < 64 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3;
-    // y < 54: (u,1) u = y-24); the remaining slots are padding with an unreachable size term
-    int s_, u1_, L_;
+    // y < 54: (u,1) u = y-24).  The spare slots carry the nine small shapes with tables of their own, told apart by a
+    // kind field: x = 58..60 the (1,2) (2,1) (2,2) loops (kinds 5..7: energy staged per cell), y = 54..59 stack (1),
+    // the two 1-bulges (2), 1x1 (3), (2,3) and (3,2) (4); what is left is padding with an unreachable size term
+    int s_, u1_, L_, kind_ = 0;
     if (x < 64) {
       const bool on = x < 58;
       u1_ = (x < 29 || !on) ? 0 : x - 27;
       s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
       L_ = on ? T.bulge[s_] : 0x3fff;
+      if (x >= 58 && x <= 60) { kind_ = x - 53; s_ = x == 60 ? 4 : 3; u1_ = x == 58 ? 1 : 2; L_ = 0; }
     } else {
       const int y = x - 64;
       const bool on = y < 54;
@@ -203,15 +211,23 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
       s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
       const int nl = s_ - 1;
       L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
+      if (y >= 54 && y <= 59) {
+        const int z = y - 54;                 // (0,0) (0,1) (1,0) (1,1) (2,3) (3,2)
+        kind_ = z == 0 ? 1 : z <= 2 ? 2 : z == 3 ? 3 : 4;
+        s_ = z == 0 ? 0 : z <= 2 ? 1 : z == 3 ? 2 : 5;
+        u1_ = z <= 1 ? 0 : z <= 3 ? 1 : z - 2;
+        L_ = 0;
+      }
     }
-    sm.eshape[x] = s_ | (u1_ << 8) | (L_ << 16);
+    sm.eshape[x] = s_ | (kind_ << 5) | (u1_ << 8) | (L_ << 16);
   }
   for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
-  for (int k = tid; k < 64; k += NT) sm.stackp[k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
-  for (int k = tid; k < 1024; k += NT) sm.int11p[k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
+  using SM = MfeFastSmem<NT>;
+  for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
+  for (int k = tid; k < 1024; k += NT) sm.xtab[SM::XT_INT11 + k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
   for (int k = tid; k < 128; k += NT) {
-    sm.mm1np[k] = sm.mm1n[k] - ((k >> 4) > 2 ? TermAU : 0);
-    sm.mm23p[k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
+    sm.xtab[SM::XT_MM1N + k] = sm.mm1n[k] - ((k >> 4) > 2 ? TermAU : 0);
+    sm.xtab[SM::XT_MM23 + k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
   }
   for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
   for (int d = TURN + 1 + wave; d < n; d += NW) {
@@ -236,7 +252,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     if (d < n) {
       mfe_prepare_tables<NT>(sm, d, tid, ninio, max_ninio);
       const int cnt = PL[d * ld + ld - 1];
-      if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
+      if (tid < cnt) { sm.plist[d & 1][tid] = PL[d * ld + tid]; sm.xe[d & 1][tid] = 0; }
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
     }
   }
@@ -296,12 +312,38 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
       if (k + 1 < n) {
         if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio);
         if (wave == w_pl) {
-          const int32_t* row = PL + (k + 1) * ld;
+          // the (1,2) (2,1) (2,2) interior loops depend on the sequence alone: their table energies (L2) are fetched
+          // here, one diagonal ahead and off the sweep waves' critical path
+          const int dn = k + 1;
+          const int32_t* row = PL + dn * ld;
           const int cnt = row[ld - 1];
-          const int p0 = row[lane], p1 = row[lane + WAVE], p2 = row[lane + 2 * WAVE], p3 = row[min(lane + 3 * WAVE, ld - 1)];
-          int* dst = sm.plist[(k + 1) & 1];
-          dst[lane] = p0; dst[lane + WAVE] = p1; dst[lane + 2 * WAVE] = p2;
-          if (lane + 3 * WAVE < MfeFastSmem<NT>::NL) dst[lane + 3 * WAVE] = p3;
+          int* dst = sm.plist[dn & 1];
+          int* dxe = sm.xe[dn & 1];
+          int pe[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) pe[c] = row[min(lane + c * WAVE, ld - 1)];
+          const int nch = __builtin_amdgcn_readfirstlane((cnt + WAVE - 1) / WAVE);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            if (c >= nch) break;                      // uniform: usually one or two chunks of 64 cells
+            const bool on = lane + c * WAVE < cnt;
+            const int i = on ? pe[c] & 255 : 1, cxv = (pe[c] >> 8) & 127, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
+            const int j = i + dn;
+            const bool va = on && dn - 5 > TURN, vc = on && dn - 6 > TURN;
+            const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
+                      tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
+            const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
+            const int s_ip2 = sm.S[i + 2], s_jm1 = sm.S[j - 1], s_jm2 = sm.S[j - 2];
+            const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
+            const int eb = T.int21[tb ? (rb * 8 + t) * 64 + s_jm1 * 16 + si1 * 4 + s_ip2 : 0];
+            const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
+            const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
+                      cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
+            if (lane + c * WAVE < MfeFastSmem<NT>::NL) {
+              dst[lane + c * WAVE] = (pe[c] & 0x7fff) | (cc << 15);
+              dxe[lane + c * WAVE] = (a & 0xffff) | (b << 16);
+            }
+          }
           if (lane == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
         }
       }
@@ -336,11 +378,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
         // ---- floating items of the diagonal, taken from a work queue (LDS counter) so the sweep waves stay
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
-        // pairable cells for the 112 bulge / 1xn shapes (E), then three groups of fixed small shapes per 64
-        // pairable cells (X).  Minima are order-free, so who takes what does not matter.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2,
-                  nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
-        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
+        // pairable cells for the 112 bulge / 1xn shapes and the nine small fixed shapes (E).  Minima are order-free,
+        // so who takes what does not matter.
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
+        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
           if (it < nK) {
             // ---- K: multiloop splits of 32 cells x 4 interleaved split-point groups.  A lane owns two adjacent cells
@@ -376,83 +417,63 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             m0 = min(m0, m2); m1 = min(m1, m3);
             if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
             if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
-          } else if (it < nK + nE) {
-            // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shapes in registers, the
-            // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer
+          } else {
+            // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in registers, the
+            // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.
+            // Slots 3 and 7 of some lanes are the nine small shapes (see the eshape table): same ring read, but the
+            // energy comes from the cell's staged values or from another table of xtab.
+            using SM = MfeFastSmem<NT>;
             const int q = 4 * (it - nK) + (lane >> 4);
-            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-            const int i0 = pe & 255, ij = pe >> 8;
+            const int qc = q < pcnt ? q : pcnt - 1;
+            const int pe = sm.plist[par][qc], xv = sm.xe[par][qc];
+            const int i0 = pe & 255, ij = (pe >> 8) & 127;
             int w[8], e_shape[8];
             bool ok[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) e_shape[k] = sm.eshape[k * 16 + (lane & 15)];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-              const int dp = d - 2 - (e_shape[k] & 255);         // diagonal of the inner pair
+              const int dp = d - 2 - (e_shape[k] & 31);          // diagonal of the inner pair
               ok[k] = dp > TURN;
-              w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 255) + i0];
+              w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 31) + i0];
             }
-            const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij];
-            int tb[4];                                           // inner-side 1xn mismatch terms: one more LDS stage
+            const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij], outer_23 = sm.mm23[ij];
+            const int kind3 = (e_shape[3] >> 5) & 7, kind7 = (e_shape[7] >> 5) & 7;
+            const int f7 = w[7] & 127, tq = (ij >> 4) * 8 + (f7 >> 4);
+            int idx7 = SM::XT_MM1N + f7;
+            idx7 = kind7 == 4 ? SM::XT_MM23 + f7 : idx7;
+            idx7 = kind7 == 3 ? SM::XT_INT11 + tq * 16 + (ij & 15) : idx7;
+            idx7 = (kind7 == 1 || kind7 == 2) ? SM::XT_STACK + tq : idx7;
+            int tb[4];                                           // inner-side terms: one more LDS stage
 #pragma unroll
-            for (int k = 0; k < 4; k++) tb[k] = sm.mm1np[w[k + 4] & 127];
+            for (int k = 0; k < 3; k++) tb[k] = sm.xtab[SM::XT_MM1N + (w[k + 4] & 127)];
+            tb[3] = sm.xtab[idx7];
+            int add3 = (e_shape[3] >> 16) + outer_b;
+            add3 = kind3 == 5 ? (xv << 16) >> 16 : add3;
+            add3 = kind3 == 6 ? xv >> 16 : add3;
+            add3 = kind3 == 7 ? pe >> 15 : add3;
+            int add7 = (e_shape[7] >> 16) + outer_o;
+            add7 = (kind7 == 1 || kind7 == 3) ? 0 : add7;
+            add7 = kind7 == 2 ? e_bulge1 : add7;
+            add7 = kind7 == 4 ? e_int23 + outer_23 : add7;
             int v = INF;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 3; k++) {
               const int e = (w[k] >> 8) + (e_shape[k] >> 16) + outer_b;
               v = min(v, ok[k] ? e : INF);
             }
+            v = min(v, ok[3] ? (w[3] >> 8) + add3 : INF);
 #pragma unroll
-            for (int k = 4; k < 8; k++) {
+            for (int k = 4; k < 7; k++) {
               const int e = (w[k] >> 8) + (e_shape[k] >> 16) + tb[k - 4] + outer_o;
               v = min(v, ok[k] ? e : INF);
             }
+            v = min(v, ok[7] ? (w[7] >> 8) + tb[3] + add7 : INF);
             v = dpp_min_i32<0x111, 0xF>(v);
             v = dpp_min_i32<0x112, 0xF>(v);
             v = dpp_min_i32<0x114, 0xF>(v);
             v = dpp_min_i32<0x118, 0xF>(v);
             if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
-          } else {
-            // ---- X: one group of fixed small shapes for 64 pairable cells (lane = compacted cell)
-            const int xi = it - nK - nE;
-            const int ch = xi / 3, grp = xi - 3 * ch;
-            const int q = ch * WAVE + lane;
-            const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
-            const int i = pe & 255, cxv = pe >> 8, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-            int v = INF;
-            if (grp == 0) {
-              // (0,0) (0,1) (1,0) (1,1): LDS tables
-              int w[4];
-#pragma unroll
-              for (int shp = 0; shp < 4; shp++) {
-                const int u1 = shp >> 1, u2 = shp == 1 || shp == 3 ? 1 : 0;
-                const int dp = d - 2 - u1 - u2;
-                w[shp] = dp > TURN ? sm.wring[(dp & 31) * RS + 1 + u1 + i] : INF * 256;
-              }
-              const int e0 = sm.stackp[t * 8 + ((w[0] & 127) >> 4)];
-              const int e1 = e_bulge1 + sm.stackp[t * 8 + ((w[1] & 127) >> 4)];
-              const int e2 = e_bulge1 + sm.stackp[t * 8 + ((w[2] & 127) >> 4)];
-              const int e3 = sm.int11p[(t * 8 + ((w[3] & 127) >> 4)) * 16 + si1 * 4 + sj1];
-              v = min(min((w[0] >> 8) + e0, (w[1] >> 8) + e1), min((w[2] >> 8) + e2, (w[3] >> 8) + e3));
-            } else if (grp == 1) {
-              // (1,2) (2,1) (2,2): tables in global memory (L2)
-              const int dpa = d - 5, dpb = d - 6;
-              const int wa = dpa > TURN ? sm.wring[(dpa & 31) * RS + 2 + i] : INF * 256;
-              const int wb = dpa > TURN ? sm.wring[(dpa & 31) * RS + 3 + i] : INF * 256;
-              const int wc = dpb > TURN ? sm.wring[(dpb & 31) * RS + 3 + i] : INF * 256;
-              const int fa = wa & 127, fb = wb & 127, fc = wc & 127;
-              const int ea = T.int21[(t * 8 + (fa >> 4)) * 64 + si1 * 16 + ((fa >> 2) & 3) * 4 + sj1] - ((fa >> 4) > 2 ? TermAU : 0);
-              const int eb = T.int21[((fb >> 4) * 8 + t) * 64 + ((fb >> 2) & 3) * 16 + si1 * 4 + (fb & 3)] - ((fb >> 4) > 2 ? TermAU : 0);
-              const int ec = T.int22[(t * 8 + (fc >> 4)) * 256 + si1 * 64 + (fc & 3) * 16 + ((fc >> 2) & 3) * 4 + sj1] - ((fc >> 4) > 2 ? TermAU : 0);
-              v = min((wa >> 8) + ea, min((wb >> 8) + eb, (wc >> 8) + ec));
-            } else {
-              // (2,3) (3,2)
-              const int dp = d - 7;
-              const int wa = dp > TURN ? sm.wring[(dp & 31) * RS + 3 + i] : INF * 256;
-              const int wb = dp > TURN ? sm.wring[(dp & 31) * RS + 4 + i] : INF * 256;
-              v = e_int23 + sm.mm23[cxv] + min((wa >> 8) + sm.mm23p[wa & 127], (wb >> 8) + sm.mm23p[wb & 127]);
-            }
-            if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i + slot0], v);
           }
         }
         STAMP(5);
