@@ -68,6 +68,11 @@ struct drna_engine {
   int* d_rpt_off = nullptr;
   std::vector<int> rt_len;
   double* d_F4 = nullptr;   // co-fold free energies (FA, FB, FcAB, FAB per pair)
+  // K-best structures: workspace for kb_chunk sequences, allocated on first use
+  int32_t* d_ws_kb = nullptr;
+  int32_t* d_kbE = nullptr;
+  char* d_kbss = nullptr;
+  int kb_chunk = 0;
   // host-mapped staging of the host-buffer entry point: the kernels read the sequences from and write their results to
   // pinned host memory directly, so a batch costs no hipMemcpy round trips (12.8 KB in, 13.6 KB out at R=64, L=200)
   char *hm_seqs = nullptr, *hm_ss = nullptr, *dm_seqs = nullptr, *dm_ss = nullptr;
@@ -172,7 +177,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   if (!e) return;
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
-                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4};
+                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -693,6 +698,82 @@ extern "C" int drna_subopt_energy_batch(drna_engine* e, int R, int L, const char
     }
   HIP_TRY(hipMemcpy(E2, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (E12) HIP_TRY(hipMemcpy(E12, e->d_Epf, (size_t)2 * R * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return DRNA_OK;
+}
+
+template <int NT, int K>
+static void launch_kbest(const KbArgs& a, int R, hipStream_t s) {
+  hipLaunchKernelGGL((kbest_kernel<NT, K>), dim3(R), dim3(NT), 0, s, a);
+}
+
+extern "C" int drna_subopt_structs_batch(drna_engine* e, int R, int L, const char* seqs, int K, int32_t* E, char* ss) {
+  if (!e) return DRNA_ERR_ARG;
+  if (R < 1 || L < 1 || L > e->max_L || K < 1 || K > 8 || !seqs || !E || !ss) {
+    e->err = "drna_subopt_structs_batch: bad argument (L within the engine's limit, 1 <= K <= 8; seqs, E and ss required)";
+    return DRNA_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const int KT = K <= 4 ? 4 : 8;                      // kernel instantiations
+  const int ldmax = e->max_L + 2;
+  const size_t stride_max = (size_t)3 * 8 * ldmax * ldmax;
+  if (!e->d_ws_kb) {
+    e->kb_chunk = e->max_R < 16 ? e->max_R : 16;
+    HIP_TRY(hipMalloc((void**)&e->d_ws_kb, stride_max * sizeof(int32_t) * e->kb_chunk));
+    HIP_TRY(hipMalloc((void**)&e->d_kbE, (size_t)8 * e->kb_chunk * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&e->d_kbss, (size_t)8 * e->kb_chunk * e->max_L));
+    e->ws_bytes += stride_max * sizeof(int32_t) * e->kb_chunk;
+  }
+  const int ld = L + 2;
+  std::vector<int32_t> hE((size_t)KT * e->kb_chunk);
+  std::vector<char> hs((size_t)KT * e->kb_chunk * L);
+  float ms_total = 0.f;
+  for (int r0 = 0; r0 < R; r0 += e->kb_chunk) {
+    const int rc = R - r0 < e->kb_chunk ? R - r0 : e->kb_chunk;
+    HIP_TRY(hipMemcpy(e->d_seqs, seqs + (size_t)r0 * L, (size_t)rc * L, hipMemcpyHostToDevice));
+    for (int k = 0; k < rc; k++) e->h_status[k] = ST_OK;
+    KbArgs a;
+    a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = e->d_seqs; a.L = L; a.ld = ld;
+    a.ws = e->d_ws_kb; a.ws_stride = (long long)3 * KT * ld * ld;
+    a.E = e->d_kbE; a.ss = e->d_kbss; a.status = e->d_status;
+    HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+    if (KT == 4) {
+      if (e->nt == 256) launch_kbest<256, 4>(a, rc, e->s_mfe);
+      else if (e->nt == 512) launch_kbest<512, 4>(a, rc, e->s_mfe);
+      else launch_kbest<1024, 4>(a, rc, e->s_mfe);
+    } else {
+      if (e->nt == 256) launch_kbest<256, 8>(a, rc, e->s_mfe);
+      else if (e->nt == 512) launch_kbest<512, 8>(a, rc, e->s_mfe);
+      else launch_kbest<1024, 8>(a, rc, e->s_mfe);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+    HIP_TRY(hipStreamSynchronize(e->s_mfe));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev_m0, e->ev_m1));
+    ms_total += ms;
+    for (int r = 0; r < rc; r++) {
+      if (e->h_status[r] == ST_BAD_CHAR) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "sequence %d holds a character other than A C G U T", r0 + r);
+        e->err = buf;
+        return DRNA_ERR_SEQUENCE;
+      }
+      if (e->h_status[r] != ST_OK) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "sequence %d: traceback of a ranked structure failed (internal error)", r0 + r);
+        e->err = buf;
+        return DRNA_ERR_INTERNAL;
+      }
+    }
+    HIP_TRY(hipMemcpy(hE.data(), e->d_kbE, (size_t)KT * rc * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hs.data(), e->d_kbss, (size_t)KT * rc * L, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rc; r++)
+      for (int k = 0; k < K; k++) {
+        E[(size_t)(r0 + r) * K + k] = hE[(size_t)r * KT + k];
+        memcpy(ss + ((size_t)(r0 + r) * K + k) * L, hs.data() + ((size_t)r * KT + k) * L, (size_t)L);
+      }
+  }
+  e->timing[0] = ms_total; e->timing[1] = e->timing[2] = 0.f; e->timing[3] = ms_total;
   return DRNA_OK;
 }
 

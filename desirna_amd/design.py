@@ -354,7 +354,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
             progress(global_step, best, stats)
     stats["elapsed_s"] = time.time() - t_start
     return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step,
-            "simulation_data": simulation_data}
+            "simulation_data": simulation_data, "engine": getattr(scorer, "engine", None)}
 
 
 def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
@@ -492,7 +492,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         if keep_records:
             simulation_data += records(step)
     stats["elapsed_s"] = time.time() - t_start
-    return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data}
+    return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data,
+            "engine": eng}
 
 
 def run_puzzle_set(inputs, rank=0, world=1, driver=None, **kw):
@@ -560,7 +561,8 @@ def main(argv=None):
                                 acc_mc_better_e=st["acc_mc_better"], rej_mc_step=st["rej_mc"], acc_re_step=st["acc_re"],
                                 rej_re_step=st["rej_re"])
         outputs.write_all(res["simulation_data"], inp.name, os.path.basename(a.name), outname, stats, st["elapsed_s"], a.timlim,
-                          time.strftime("%Y%m%d.%H%M%S"), directory=a.outdir)
+                          time.strftime("%Y%m%d.%H%M%S"), directory=a.outdir,
+                          alt_sec_structs=list(inp.alt_sec_structs or []) or None, engine=res.get("engine"))
     b = res["best"]
     print("Design solved succesfully!" if res["solved"] else "Design not solved.")
     print(b.sequence)

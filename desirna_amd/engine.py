@@ -24,7 +24,8 @@ _ERRORS = {-1: "bad argument", -2: "bad parameter blob", -3: "HIP/device error",
 EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets", "drna_score_batch",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch")
+           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
+           "drna_subopt_structs_batch")
 
 
 class EngineError(RuntimeError):
@@ -75,6 +76,8 @@ def load_library(path=None):
                               C.c_double, ci, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.drna_subopt_energy_batch.restype = ci
     L.drna_subopt_energy_batch.argtypes = [vp, ci, ci, C.c_char_p, vp, vp]
+    L.drna_subopt_structs_batch.restype = ci
+    L.drna_subopt_structs_batch.argtypes = [vp, ci, ci, C.c_char_p, ci, vp, vp]
     L.drna_simscore_batch.restype = ci
     L.drna_simscore_batch.argtypes = [ci, ci, C.c_char_p, vp, vp, vp, vp]
     L.drna_propose_batch.restype = ci
@@ -255,6 +258,21 @@ class Engine:
                                                      E12.ctypes.data if want_both else None))
         return (E2, E12) if want_both else E2
 
+    def subopt_structs(self, seqs, K):
+        """The K (<= 8) lowest-energy structures of each sequence: (R, K) int32 energies in dcal/mol (ascending; 10000000 where
+        a sequence has fewer structures) and a list of R lists of K dot-bracket strings.  Rank k is entry k of ViennaRNA's
+        energy-sorted subopt list as get_first_suboptimal_structure_and_energy(seq, fc, k) indexes it (reference
+        utils/energy_scores.py:453-488); the order among structures of equal energy is the engine's own."""
+        R, L = len(seqs), len(seqs[0])
+        if any(len(s) != L for s in seqs):
+            raise ValueError("all sequences of a batch must have the same length")
+        E = np.zeros((R, K), dtype=np.int32)
+        ss = np.zeros((R, K, L), dtype=np.uint8)
+        self._check(self._L.drna_subopt_structs_batch(self._h, R, L, "".join(seqs).encode("ascii"), int(K), E.ctypes.data,
+                                                      ss.ctypes.data))
+        raw = ss.tobytes().decode("ascii")
+        return E, [[raw[(r * K + k) * L:(r * K + k + 1) * L] for k in range(K)] for r in range(R)]
+
     def ensemble_defect(self, seqs, want_bpp=False):
         """Ensemble defect of each sequence against targets[0] (reference ScoreSeq.get_ensemble_defect,
         utils/energy_scores.py:362-374).  Returns float64[R]; with want_bpp also the (R, L+1, L+1) base-pair
@@ -376,6 +394,5 @@ class HostKernels:
         rc = self._L.drna_metropolis_batch(R, so.ctypes.data, sm.ctypes.data, tt.ctypes.data, float(L_const),
                                            rng_state.ctypes.data, acc.ctypes.data, bet.ctypes.data)
         if rc != 0:
-            raise EngineError(rc, "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
-           "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch")
+            raise EngineError(rc, "drna_metropolis_batch")
         return acc.astype(bool), bet.astype(bool)

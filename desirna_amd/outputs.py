@@ -2,7 +2,7 @@
 
 Counterpart of ``utils/stats_inputs_outputs.py``: ``sort_trajectory`` / ``generate_trajectory_csv`` (:304-335),
 ``generate_multifasta`` (:337-358), ``generate_best_fasta`` (:360-382), ``sort_and_filter_simulation_data`` (:384-430, the
-single-chain branch), ``generate_csv_from_data`` (:463-478), ``check_if_design_solved`` / ``write_best_str_file``
+single-chain branch), ``sort_and_filter_simulation_data_alternative`` (:422-460, with ``get_alt_mcc``), ``generate_csv_from_data`` (:463-478), ``check_if_design_solved`` / ``write_best_str_file``
 (:480-524), ``generate_simulation_stats_text`` / ``write_stats_to_file`` (:526-577), ``get_outname`` (:636-669) and of
 ``round_floats`` (``utils/sequence_utils.py:1254-1274``).  A record is ``vars(ScoreSeq)``: the CSV header is its key order.
 
@@ -64,6 +64,51 @@ def sort_and_filter(simulation_data, num_results=10):
     return res[:num_results]
 
 
+def get_alt_mcc(simulation_data, alt_sec_structs, engine):
+    """1-MCC of every alternative target against the sequence's k-th sub-optimal structure (k = 1 .. #alternatives), added to
+    the records as ``mcc_k`` / ``alt_struct_k`` -- reference ``get_alt_mcc`` (``utils/sequence_utils.py:766-793``) on top of
+    ``get_first_suboptimal_structure_and_energy`` (``utils/energy_scores.py:453-488``: entry k of the energy-sorted subopt list
+    found within at most 49 kcal/mol of the ground state, else all dots).  The ranked structures of all records come from
+    one ``engine.subopt_structs`` call per sequence length (GPU; no CPU fallback)."""
+    from .sim_score import SimScore
+    n_alt = len(alt_sec_structs)
+    if not simulation_data or not n_alt:
+        return simulation_data
+    if n_alt > 7:
+        raise ValueError("at most 7 alternative structures (the engine ranks up to 8 structures per sequence)")
+    by_len = {}
+    for i, d in enumerate(simulation_data):
+        if "&" in d["sequence"]:
+            raise ValueError("ranked sub-optimal structures are single-strand only")
+        by_len.setdefault(len(d["sequence"]), []).append(i)
+    for L, idx in by_len.items():
+        E, ss = engine.subopt_structs([simulation_data[i]["sequence"] for i in idx], n_alt + 1)
+        for row, i in enumerate(idx):
+            for k in range(1, n_alt + 1):
+                ok = E[row, k] < 10000000 and int(E[row, k]) - int(E[row, 0]) <= 4900
+                sub = ss[row][k] if ok else "." * L
+                sc = SimScore(alt_sec_structs[k - 1].replace("&", "Ee"), sub.replace("&", "Ee"))
+                sc.find_basepairs()
+                sc.cofusion_matrix()
+                simulation_data[i]["mcc_" + str(k)] = 1 - sc.mcc()
+                simulation_data[i]["alt_struct_" + str(k)] = sub
+    return simulation_data
+
+
+def sort_and_filter_alternative(simulation_data, alt_sec_structs, engine, num_results=10):
+    """Final ranking of an alternative-structure design (reference ``sort_and_filter_simulation_data_alternative``,
+    ``utils/stats_inputs_outputs.py:422-460``): unique sequences sorted as in ``sort_and_filter``, ``get_alt_mcc`` on all
+    of them, then best first by 1-MCC of the target and of every alternative, 1-MCC again, scoring function.  Returns
+    (top records, all records with the added columns -- the reference rewrites ``_traj.csv`` from the latter)."""
+    uniq = list({item['sequence']: item for item in simulation_data}.values())
+    first = sorted(_round_records(uniq), key=lambda d: (-d['mcc'], -d['edesired_minus_Epf'], -d['Epf'], -d['scoring_function']),
+                   reverse=True)
+    aug = get_alt_mcc(first, alt_sec_structs, engine)
+    cols = ['mcc'] + ["mcc_" + str(k + 1) for k in range(len(alt_sec_structs))]
+    res = sorted(_round_records(aug), key=lambda d: tuple([-d[c] for c in cols] + [-d['mcc'], -d['scoring_function']]), reverse=True)
+    return res[:num_results], aug
+
+
 def results_csv_text(sorted_results):
     return _csv_text(sorted_results)
 
@@ -101,9 +146,11 @@ def get_outname(infile, replicas, RE_attempt, timlim, pks, acgu_percentages, T_m
             "_O" + str(oligo) + "_D" + str(dimer) + "_PM" + str(point_mutations))
 
 
-def write_all(simulation_data, input_name, infile, outname, stats, finish_time, timlim, now, num_results=10, directory="."):
+def write_all(simulation_data, input_name, infile, outname, stats, finish_time, timlim, now, num_results=10, directory=".",
+              alt_sec_structs=None, engine=None):
     """Write _traj.csv, _multifasta.fas, _best_fasta.fas, _results.csv, _best_str and _stats (reference
-    parse_and_output_results, :593-633).  Returns (sorted_results, solved)."""
+    parse_and_output_results, :593-633).  With alternative structures the ranking is sort_and_filter_alternative and
+    _traj.csv is rewritten from its augmented records, as the reference does.  Returns (sorted_results, solved)."""
     import os
     base = os.path.join(directory, outname)
     traj = sort_trajectory(simulation_data)
@@ -113,7 +160,12 @@ def write_all(simulation_data, input_name, infile, outname, stats, finish_time, 
         fh.write(multifasta_text(traj, infile, now))
     with open(base + '_best_fasta.fas', 'w', encoding='utf-8') as fh:
         fh.write(best_fasta_text(simulation_data, infile, now, num_results))
-    res = sort_and_filter(simulation_data, num_results)
+    if alt_sec_structs:
+        res, aug = sort_and_filter_alternative(simulation_data, alt_sec_structs, engine, num_results)
+        with open(base + '_traj.csv', 'w', newline='', encoding='utf-8') as fh:
+            fh.write(trajectory_csv_text(aug))
+    else:
+        res = sort_and_filter(simulation_data, num_results)
     with open(base + '_results.csv', 'w', newline='', encoding='utf-8') as fh:
         fh.write(results_csv_text(res))
     txt, ok = check_if_design_solved(res[:10], input_name)

@@ -131,6 +131,19 @@ int drna_cofold_batch(drna_engine *e, int R, int L, int cut, const char *seqs, u
 int drna_subopt_energy_batch(drna_engine *e, int R, int L, const char *seqs, int32_t *E2, int32_t *E12);
 
 /*
+ * The K lowest-energy structures of R sequences, energies and dot-bracket strings.  Replaces
+ * get_first_suboptimal_structure_and_energy(seq, fc, k)[0] for k = 1 .. #alternative structures, the call behind
+ * get_alt_mcc() (utils/sequence_utils.py:766-793, utils/energy_scores.py:453-488): entry k of ViennaRNA's energy-sorted
+ * subopt list (uniq_ML = 1) is rank k here (rank 0 = a ground state).  Structures of equal energy come in this engine's
+ * own fixed order (ViennaRNA's order among ties is pinned nowhere in the reference).  R is not limited by max_R (the
+ * batch is worked off in chunks).
+ *   K    1 .. 8
+ *   E    R*K int32, dcal/mol, ascending per sequence; 10000000 where the sequence has fewer than rank+1 structures
+ *   ss   R*K*L chars (no terminator); all dots where E = 10000000
+ */
+int drna_subopt_structs_batch(drna_engine *e, int R, int L, const char *seqs, int K, int32_t *E, char *ss);
+
+/*
  * Ensemble defect of R sequences against targets[0] (needs drna_set_targets with the same L): inside fill,
  * outside recursion, base-pair probabilities, then (1/L) * [ sum_{i unpaired in target} sum_j P(i,j)
  * + sum_{i paired with m in target} (1 - P(i,m)) ], '(' ')' pairs only.

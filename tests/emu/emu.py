@@ -24,6 +24,7 @@ def build():
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
     L.emu_subopt.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp, vp]
+    L.emu_kbest.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp]
     L.emu_edef.argtypes = [vp, ci, ci, ci, C.c_char_p, vp, ci, vp, vp, vp]
     return L
 
@@ -150,3 +151,15 @@ class Emu:
                                E12.ctypes.data, st.ctypes.data)
         assert rc == 0
         return E2, E12, st
+
+    def kbest(self, seqs, K, nt=128):
+        """K lowest-energy structures: (R, K) energies, R lists of K strings, status"""
+        R, L = len(seqs), len(seqs[0])
+        E = np.zeros((R, K), dtype=np.int32)
+        ss = np.zeros((R, K, L), dtype=np.uint8)
+        st = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_kbest(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), nt, K, E.ctypes.data,
+                              ss.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        raw = ss.tobytes().decode("ascii")
+        return E, [[raw[(r * K + k) * L:(r * K + k + 1) * L] for k in range(K)] for r in range(R)], st

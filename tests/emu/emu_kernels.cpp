@@ -217,4 +217,28 @@ int emu_subopt(const int32_t* blob, int n_int32, int R, int L, const char* seqs,
   delete c;
   return 0;
 }
+// K lowest-energy structures (energies + strings) of R sequences
+int emu_kbest(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int nt, int K, int32_t* E, char* ss, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  const size_t stride = (size_t)3 * K * ld * ld;
+  std::vector<int32_t> ws(stride, 0);
+  for (int r = 0; r < R; r++) {
+    KbArgs a;
+    a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data(); a.seqs = seqs; a.L = L; a.ld = ld;
+    a.ws = ws.data() - (size_t)r * stride; a.ws_stride = (long long)stride;
+    a.E = E; a.ss = ss; a.status = status;
+    if (K == 4) {
+      if (nt == 64) emu_launch(r, 64, [&]() { kbest_kernel<64, 4>(a); });
+      else emu_launch(r, 128, [&]() { kbest_kernel<128, 4>(a); });
+    } else if (K == 8) {
+      if (nt == 64) emu_launch(r, 64, [&]() { kbest_kernel<64, 8>(a); });
+      else emu_launch(r, 128, [&]() { kbest_kernel<128, 8>(a); });
+    } else { delete c; return -2; }
+  }
+  delete c;
+  return 0;
 }
+}
+

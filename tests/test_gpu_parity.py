@@ -389,6 +389,51 @@ def test_subopt_energy_vs_oracle(eng400, oracle):
             assert int(E12[k, 0]) == oracle.mfe(s)[1]
 
 
+def test_ranked_structures(eng400, oracle):
+    """K lowest-energy structures (the call behind get_alt_mcc): energies ascending, rank 0 = MFE, rank 1 =
+    the oracle's second-best energy, every string distinct and worth exactly its energy (oracle.eval_structure); short
+    sequences against explicit enumeration in tests/test_kernels_emulated.py."""
+    rng = np.random.default_rng(78)
+    for L, K in ((5, 4), (13, 4), (36, 8), (100, 4), (200, 3), (260, 8)):
+        seqs = [_rand(rng, L) for _ in range(3)] + [_rand(rng, L, "GC"), "A" * L]
+        E, ss = eng400.subopt_structs(seqs, K)
+        for k, s in enumerate(seqs):
+            e = [int(x) for x in E[k]]
+            assert e == sorted(e), s
+            two = oracle.two_best(s)
+            assert e[0] == oracle.mfe(s)[1] == two[0] and (K < 2 or e[1] == two[1]), s
+            real = [x for x, v in zip(ss[k], e) if v < 10000000]
+            assert len(set(real)) == len(real), s
+            for x, v in zip(ss[k], e):
+                if v < 10000000:
+                    assert oracle.eval_structure(s, x) == v, (s, x)
+                else:
+                    assert x == "." * L
+
+
+def test_get_alt_mcc_records(eng400, oracle):
+    """outputs.get_alt_mcc / sort_and_filter_alternative (reference sequence_utils.py:766-793, stats_inputs_outputs.py:422-460)."""
+    from desirna_amd import outputs
+    from desirna_amd.sim_score import SimScore
+    rng = np.random.default_rng(79)
+    L = 40
+    alts = ["((((....))))" + "." * (L - 12), "." * (L - 12) + "((((....))))"]
+    seqs = [_rand(rng, L) for _ in range(6)]
+    recs = [{"sequence": s, "mcc": 0.1 * (k % 3), "edesired_minus_Epf": 1.0 + k, "Epf": -3.0, "scoring_function": 0.5 * k}
+            for k, s in enumerate(seqs)] + [{"sequence": seqs[0], "mcc": 0.0, "edesired_minus_Epf": 9.0, "Epf": -1.0, "scoring_function": 7.0}]
+    top, aug = outputs.sort_and_filter_alternative(recs, alts, eng400, num_results=4)
+    assert len(aug) == 6 and len(top) == 4
+    E, ss = eng400.subopt_structs(seqs, 3)
+    for d in aug:
+        k = seqs.index(d["sequence"])
+        for a in (1, 2):
+            assert d["alt_struct_%d" % a] == ss[k][a]
+            sc = SimScore(alts[a - 1], ss[k][a]); sc.find_basepairs(); sc.cofusion_matrix()
+            assert d["mcc_%d" % a] == 1 - sc.mcc()
+    keys = [(d["mcc"], d["mcc_1"], d["mcc_2"]) for d in top]
+    assert keys == sorted(keys)
+
+
 def test_negative_design_scoring(eng400, oracle, traj_golden, example_inputs):
     """-nd on through ReplicaScorer (reference energy_scores.py:105-108): for candidates whose MFE structure is the target
     the scoring function loses (E_subopt - Epf)."""

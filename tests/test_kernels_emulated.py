@@ -160,3 +160,45 @@ def test_subopt_kernel_two_best(emu, oracle):
             assert tuple(int(x) for x in E12[k]) == oracle.two_best(s), s
             assert int(E2[k]) == oracle.subopt_energy(s), s
             assert int(E12[k, 0]) == oracle.mfe(s)[1]
+
+
+# ---- K lowest-energy structures with their strings (kbest_kernel), the call behind get_alt_mcc: checked against
+# explicit enumeration of every structure of short sequences (the reference pins nothing here)
+
+def _all_structures(seq):
+    n = len(seq)
+    pairs = {("A", "U"), ("U", "A"), ("G", "C"), ("C", "G"), ("G", "U"), ("U", "G")}
+    out = []
+
+    def rec(i, cur, stack):
+        if i == n:
+            if not stack:
+                out.append("".join(cur))
+            return
+        cur.append("."); rec(i + 1, cur, stack); cur.pop()
+        if n - i - 1 >= len(stack) + 1:
+            cur.append("("); stack.append(i); rec(i + 1, cur, stack); stack.pop(); cur.pop()
+        if stack and i - stack[-1] > 3 and (seq[stack[-1]], seq[i]) in pairs:
+            o = stack.pop(); cur.append(")"); rec(i + 1, cur, stack); cur.pop(); stack.append(o)
+
+    rec(0, [], [])
+    return out
+
+
+def test_kbest_structures_against_enumeration(emu, oracle):
+    rng = np.random.default_rng(77)
+    cases = [(_rand(rng, 13), 4, 64), (_rand(rng, 15, "GC"), 4, 128), (_rand(rng, 14, "GCAU"), 8, 64), ("GGGAAACCCA", 4, 64),
+             ("AAAAAAAA", 4, 64)]
+    for s, K, nt in cases:
+        E, ss, st = emu.kbest([s], K, nt=nt)
+        assert not st.any()
+        en = sorted(oracle.eval_structure(s, x) for x in _all_structures(s))
+        want = (en + [10000000] * K)[:K]
+        assert [int(x) for x in E[0]] == want, s
+        got = [x for x, e in zip(ss[0], E[0]) if e < 10000000]
+        assert len(set(got)) == len(got), (s, got)                      # K different structures
+        for x, e in zip(ss[0], E[0]):
+            if e < 10000000:
+                assert oracle.eval_structure(s, x) == int(e), (s, x)    # each string has the energy reported for it
+            else:
+                assert x == "." * len(s)
