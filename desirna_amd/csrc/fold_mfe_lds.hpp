@@ -383,6 +383,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+          STAMP(6);
           if (it < nK) {
             // ---- K: multiloop splits of 32 cells x 4 interleaved split-point groups.  A lane owns two adjacent cells
             // (one ds_read2 per operand pair) and walks the compact triangle with running offsets: row tt starts
@@ -417,6 +418,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             m0 = min(m0, m2); m1 = min(m1, m3);
             if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
             if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
+            STAMP(5);
+#ifdef DRNA_STAMPS
+            st_acc[7]++;
+#endif
           } else {
             // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in registers, the
             // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.
@@ -474,9 +479,13 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             v = dpp_min_i32<0x114, 0xF>(v);
             v = dpp_min_i32<0x118, 0xF>(v);
             if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
+            STAMP(1);
+#ifdef DRNA_STAMPS
+            st_acc[2]++;
+#endif
           }
         }
-        STAMP(5);
+        STAMP(6);
       }
       __syncthreads();
       STAMP(3);

@@ -24,10 +24,10 @@ buf = np.zeros(16 * 8 * 2, dtype=np.int32)
 eng._L.drna_debug_read_mfe_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
 rc = eng._L.drna_debug_read_mfe_ws(eng._h, 2 * ld * ld, buf.size, buf.ctypes.data)
 st = buf.view(np.int64).reshape(16, 8)
-names = ["T", "E", "X", "barrier", "finalize", "K"]
+names = ["T", "E", "#E-items", "barrier", "finalize", "K", "pop", "#K-items"]
 print("per-wave cycles (block 0), total over %d diagonals" % (L - 4))
 for w in range(16):
-    print("wave %2d " % w + "  ".join("%s=%7d" % (names[k], st[w, k]) for k in range(6)), " sum=%d" % st[w, :6].sum())
+    print("wave %2d " % w + "  ".join("%s=%7d" % (names[k], st[w, k]) for k in range(8)), " sum=%d" % (st[w, :7].sum() - st[w, 2]))
 
 
 # ---- PF kernel: stamps live in the (unused) U table of block 0
