@@ -118,12 +118,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    # DRNA_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: the ranks share the card (local_rank modulo the device
+    # count) and the score gather goes through host tensors, so the launch contract (env, barriers, max over ranks, one JSON
+    # line from rank 0) can be exercised without RCCL.  Real runs use the default, RCCL, one rank per GPU.
+    backend = os.environ.get("DRNA_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
+    if world > 1:
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if backend == "gloo" else dev      # where the collectives' tensors live
 
     from desirna_amd import engine as E
     target = load_target(args.target)
@@ -143,7 +154,7 @@ def main():
     d_Emfe = torch.zeros(R, dtype=torch.int32, device=dev)
     d_ss = torch.zeros(R * L, dtype=torch.uint8, device=dev)
     d_Ed = torch.zeros(R, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(R * world, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(R * world, dtype=torch.float64, device=cdev) if world > 1 else None
     torch.cuda.synchronize()
 
     def step(k, last):
@@ -151,7 +162,7 @@ def main():
                                d_ss.data_ptr(), d_Ed.data_ptr())
         if world > 1 and (last or (k + 1) % args.exchange_every == 0):
             score = d_Ed.to(torch.float64) / 100.0 - d_Epf          # Ed - Epf, the default -sf term
-            dist.all_gather_into_tensor(gathered, score)
+            dist.all_gather_into_tensor(gathered, score.to(cdev))
 
     for k in range(args.warmup):
         step(k, False)
@@ -170,7 +181,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     for key in tk:

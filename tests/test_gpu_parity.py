@@ -411,6 +411,24 @@ def test_ranked_structures(eng400, oracle):
                     assert x == "." * L
 
 
+def test_ranked_structures_chunks_and_errors(eng400, oracle):
+    """more sequences than one workspace chunk (16): results do not depend on the chunk a sequence lands in; error codes"""
+    from desirna_amd.engine import EngineError
+    rng = np.random.default_rng(80)
+    seqs = [_rand(rng, 30) for _ in range(37)]
+    E, ss = eng400.subopt_structs(seqs, 2)
+    E1, ss1 = eng400.subopt_structs(seqs[20:23], 2)
+    assert (E[20:23] == E1).all() and ss[20:23] == ss1
+    for k, s in enumerate(seqs):
+        assert tuple(int(x) for x in E[k]) == oracle.two_best(s), s
+    with pytest.raises(EngineError) as ei:
+        eng400.subopt_structs(["ACGUXACGUA"], 2)
+    assert ei.value.code == -4
+    with pytest.raises(EngineError) as ei:
+        eng400.subopt_structs(["ACGUACGUA"], 9)
+    assert ei.value.code == -1
+
+
 def test_get_alt_mcc_records(eng400, oracle):
     """outputs.get_alt_mcc / sort_and_filter_alternative (reference sequence_utils.py:766-793, stats_inputs_outputs.py:422-460)."""
     from desirna_amd import outputs
