@@ -389,6 +389,23 @@ def test_subopt_energy_vs_oracle(eng400, oracle):
             assert int(E12[k, 0]) == oracle.mfe(s)[1]
 
 
+def test_maximum_length(oracle):
+    """the engine's length limit (MAXN - 2 = 2046 nt, general kernels): same bits as the oracle"""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(4242)
+    for L in (601, 2046):
+        seqs = [_rand(rng, L)]
+        eng = E.Engine(max_R=1, max_L=L, device=0)
+        eng.set_targets(["." * L])
+        out = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+        ss, e = oracle.mfe(seqs[0])
+        assert out["mfe_ss"][0] == ss and int(out["Emfe"][0]) == e and int(out["Ed"][0, 0]) == 0
+        assert abs(float(out["Epf"][0]) - oracle.pf(seqs[0])) < 1e-9
+        eng.close()
+    with pytest.raises(Exception):
+        E.Engine(max_R=1, max_L=2047, device=0)
+
+
 def test_ranked_structures(eng400, oracle):
     """K lowest-energy structures (the call behind get_alt_mcc): energies ascending, rank 0 = MFE, rank 1 =
     the oracle's second-best energy, every string distinct and worth exactly its energy (oracle.eval_structure); short
