@@ -69,6 +69,14 @@ __device__ __forceinline__ int as_vector(int x) { return __builtin_amdgcn_update
 // Pin a loop-invariant value loaded from global memory in registers: without this hipcc re-executes the load
 // inside the diagonal loop (cheaper in registers, but a full L2 round trip per diagonal on the critical path).
 __device__ __forceinline__ int keep_i32(int x) { return as_vector(x); }
+
+// kind of plan entry e from the first entries of the kinds (scalar compares; entries past the last special kind are generic)
+__device__ __forceinline__ int plan_kind(const int (&seg)[PK_NKINDS], int e) {
+  int k = 0;
+#pragma unroll
+  for (int x = 1; x < PK_NKINDS; x++) k += e >= seg[x];
+  return k;
+}
 __device__ __forceinline__ double keep_f64(double x) {
   return __hiloint2double(as_vector(__double2hiint(x)), as_vector(__double2loint(x)));
 }

@@ -59,6 +59,8 @@ struct MfeSmem : MfeSmemCore<MAXN> {
   // pairable cells of a diagonal, compacted (ascending i), and the inverse map; double-buffered by diagonal parity
   unsigned short plist[2][MAXN], cpos[2][MAXN + 2];
   int pcnt[2];
+  // interior-loop plan staged from HBM: u1 | u2 << 8 | kind << 16, and the size term
+  int plan_u[NPLAN], plan_L[NPLAN];
 };
 
 // one wave: list of the cells (i, i+d) that can pair (hard constraints of the pseudoknot rounds included)
@@ -165,6 +167,8 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());   // SGPR: items, plan entries and branches stay scalar
   const int INF = INF_DEV, HALF = INF_DEV / 2;
   const int segG = P.seg[PK_GENERIC];
+  int seg[PK_NKINDS];                   // first entry of every kind (wave-uniform: the kind of an entry stays scalar)
+  for (int k = 0; k < PK_NKINDS; k++) seg[k] = P.seg[k];
 
   // rows read before they are written: fML diag 3, decomp diags 2 and 3
   for (int k = tid; k < ld; k += NT) {
@@ -172,6 +176,7 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
     DML[2 * ld + k] = INF;
     DML[3 * ld + k] = INF;
   }
+  for (int e = tid; e < NPLAN; e += NT) { sm.plan_u[e] = P.u1[e] | (P.u2[e] << 8) | (P.kind[e] << 16); sm.plan_L[e] = P.L[e]; }
   if (wave == 0 && TURN + 1 < n) mfe_build_plist(sm, TURN + 1, n, lane);
   __syncthreads();
   const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)((long long)ld * ld * 4), 0x00020000);
@@ -200,36 +205,63 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
         const int ij = t * 16 + si1 * 4 + sj1;
         int accI = INF;
         const int tau = t > 2 ? T.TermAU : 0;
+        // Four plan entries per pass, written as stages (entries from LDS, then the four table loads, then the
+        // arithmetic): one L2 round trip per four entries instead of two per entry.
         // special kinds (stack, bulges, 1x1, 2x1, 1xn, 2x2, 2x3): strided over the chunk
-        for (int e = h; e < segG; e += HI) {
-          const int u1 = P.u1[e], u2 = P.u2[e];
-          const int dp = d - 2 - u1 - u2;
-          if (dp <= TURN) continue;
-          const int w = Wc[dp * ld + i + 1 + u1];
-          const int cpq = w >> 8, info = w & 127, t2 = info >> 4;
-          int en;
-          switch (P.kind[e]) {
-            case PK_STACK: en = cpq + sm.stack[t * 8 + t2]; break;
-            case PK_BULGE1: en = cpq + P.L[e] + sm.stack[t * 8 + t2]; break;
-            case PK_BULGEN: en = cpq + P.L[e] + tau + (t2 > 2 ? T.TermAU : 0); break;
-            case PK_INT11: en = cpq + sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
-            case PK_INT21: en = cpq + T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
-            case PK_INT12: en = cpq + T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
-            case PK_1XN: en = cpq + P.L[e] + sm.mm1n[ij] + sm.mm1n[info]; break;
-            case PK_INT22:
-              en = cpq + T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
-              break;
-            default: /* PK_INT23 */ en = cpq + P.L[e] + sm.mm23[ij] + sm.mm23[info]; break;
+        for (int e = h; e < segG; e += 4 * HI) {
+          int pu[4], pl[4], w[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int ee = as_vector(min(e + k * HI, segG - 1));
+            pu[k] = sm.plan_u[ee]; pl[k] = sm.plan_L[ee];
           }
-          accI = min(accI, en);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            const int dp = d - 2 - u1 - u2;
+            ok[k] = e + k * HI < segG && dp > TURN;
+            w[k] = Wc[ok[k] ? dp * ld + i + 1 + u1 : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int cpq = w[k] >> 8, info = w[k] & 127, t2 = info >> 4;
+            int en;
+            switch (plan_kind(seg, e + k * HI)) {
+              case PK_STACK: en = cpq + sm.stack[t * 8 + t2]; break;
+              case PK_BULGE1: en = cpq + pl[k] + sm.stack[t * 8 + t2]; break;
+              case PK_BULGEN: en = cpq + pl[k] + tau + (t2 > 2 ? T.TermAU : 0); break;
+              case PK_INT11: en = cpq + sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+              case PK_INT21: en = cpq + T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
+              case PK_INT12: en = cpq + T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
+              case PK_1XN: en = cpq + pl[k] + sm.mm1n[ij] + sm.mm1n[info]; break;
+              case PK_INT22:
+                en = cpq + T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
+                break;
+              default: /* PK_INT23 */ en = cpq + pl[k] + sm.mm23[ij] + sm.mm23[info]; break;
+            }
+            accI = min(accI, ok[k] ? en : INF);
+          }
         }
         // generic interior loops: c + mismatchI(inner) precombined in CI, size term is a scalar
         int accG = INF;
-        for (int e = segG + h; e < NPLAN; e += HI) {
-          const int u1 = P.u1[e];
-          const int dp = d - 2 - u1 - P.u2[e];
-          if (dp <= TURN) continue;
-          accG = min(accG, CI[dp * ld + i + 1 + u1] + P.L[e]);
+        for (int e = segG + h; e < NPLAN; e += 4 * HI) {
+          int pu[4], pl[4], v[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int ee = as_vector(min(e + k * HI, NPLAN - 1));
+            pu[k] = sm.plan_u[ee]; pl[k] = sm.plan_L[ee];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            const int dp = d - 2 - u1 - u2;
+            ok[k] = e + k * HI < NPLAN && dp > TURN;
+            v[k] = CI[ok[k] ? dp * ld + i + 1 + u1 : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) accG = min(accG, ok[k] ? v[k] + pl[k] : INF);
         }
         accI = min(accI, accG + sm.mmI[ij]);
         sm.partI[item * WAVE + lane] = accI;

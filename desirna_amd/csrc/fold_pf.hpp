@@ -46,6 +46,9 @@ struct PfSmem {
   int pcnt[2];
   unsigned char S[MAXN + 4];
   int flag;
+  // interior-loop plan staged from HBM: u1 | u2 << 8 | kind << 16, and the Boltzmann factor of the size term
+  int plan_u[NPLAN];
+  double plan_W[NPLAN];
 };
 
 // one wave: list of the cells (i, i+d) that can pair
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int segG = P.seg[PK_GENERIC];
+  int seg[PK_NKINDS];                   // first entry of every kind (wave-uniform: the kind of an entry stays scalar)
+  for (int k = 0; k < PK_NKINDS; k++) seg[k] = P.seg[k];
 
   double* base = A.ws + (long long)r * A.ws_stride;
   const long long tab = (long long)ld * ld;
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   }
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  for (int e = tid; e < NPLAN; e += NT) { sm.plan_u[e] = P.u1[e] | (P.u2[e] << 8) | (P.kind[e] << 16); sm.plan_W[e] = P.W[e]; }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
   const char* seq = A.seqs + (A.rg.off ? (long long)A.rg.off[r] : (long long)r * n);
@@ -183,35 +189,65 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
         const int ij = t * 16 + si1 * 4 + sj1;
         double accI = 0.0;
         const double tau = t > 2 ? T.TermAU : 1.0;
-        for (int e = h; e < segG; e += HI) {
-          const int u1 = P.u1[e], u2 = P.u2[e];
-          const int dp = d - 2 - u1 - u2;
-          if (dp <= TURN) continue;
-          const int at = dp * ld + i + 1 + u1;
-          const double qpq = QB[at];
-          const int info = INFO[at], t2 = info >> 4;
-          double f;
-          switch (P.kind[e]) {
-            case PK_STACK: f = sm.stack[t * 8 + t2]; break;
-            case PK_BULGE1: f = sm.stack[t * 8 + t2]; break;
-            case PK_BULGEN: f = tau * (t2 > 2 ? T.TermAU : 1.0); break;
-            case PK_INT11: f = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
-            case PK_INT21: f = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
-            case PK_INT12: f = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
-            case PK_1XN: f = sm.mm1n[ij] * sm.mm1n[info]; break;
-            case PK_INT22:
-              f = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
-              break;
-            default: /* PK_INT23 */ f = sm.mm23[ij] * sm.mm23[info]; break;
+        // Four plan entries per pass, written as stages (entries from LDS, then the table loads, then the arithmetic):
+        // one L2 round trip per four entries instead of two per entry.  The order of the sum is fixed by (h, HI).
+        for (int e = h; e < segG; e += 4 * HI) {
+          int pu[4], info4[4];
+          double pw[4], qpq[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int ee = as_vector(min(e + k * HI, segG - 1));
+            pu[k] = sm.plan_u[ee]; pw[k] = sm.plan_W[ee];
           }
-          accI += qpq * f * P.W[e];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            const int dp = d - 2 - u1 - u2;
+            ok[k] = e + k * HI < segG && dp > TURN;
+            const int at = ok[k] ? dp * ld + i + 1 + u1 : 0;
+            qpq[k] = QB[at];
+            info4[k] = INFO[at] & 127;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int info = info4[k], t2 = info >> 4;
+            double f;
+            switch (plan_kind(seg, e + k * HI)) {
+              case PK_STACK: f = sm.stack[t * 8 + t2]; break;
+              case PK_BULGE1: f = sm.stack[t * 8 + t2]; break;
+              case PK_BULGEN: f = tau * (t2 > 2 ? T.TermAU : 1.0); break;
+              case PK_INT11: f = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+              case PK_INT21: f = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
+              case PK_INT12: f = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
+              case PK_1XN: f = sm.mm1n[ij] * sm.mm1n[info]; break;
+              case PK_INT22:
+                f = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
+                break;
+              default: /* PK_INT23 */ f = sm.mm23[ij] * sm.mm23[info]; break;
+            }
+            if (ok[k]) accI += qpq[k] * f * pw[k];
+          }
         }
         double accG = 0.0;
-        for (int e = segG + h; e < NPLAN; e += HI) {
-          const int u1 = P.u1[e];
-          const int dp = d - 2 - u1 - P.u2[e];
-          if (dp <= TURN) continue;
-          accG += QBI[dp * ld + i + 1 + u1] * P.W[e];
+        for (int e = segG + h; e < NPLAN; e += 4 * HI) {
+          int pu[4];
+          double pw[4], v[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int ee = as_vector(min(e + k * HI, NPLAN - 1));
+            pu[k] = sm.plan_u[ee]; pw[k] = sm.plan_W[ee];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            const int dp = d - 2 - u1 - u2;
+            ok[k] = e + k * HI < NPLAN && dp > TURN;
+            v[k] = QBI[ok[k] ? dp * ld + i + 1 + u1 : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (ok[k]) accG += v[k] * pw[k];
         }
         accI += accG * sm.mmI[ij];
         sm.partI[item * WAVE + lane] = accI;

@@ -72,9 +72,9 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_exchan
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   (void)bank_mask;
   const int L = threadIdx.x & 63, r = L >> 4;
+  if (ctrl == 0xE4) return src;        // identity quad_perm (as_vector()): no lane talks to another, no rendezvous needed
   int from = -1;
-  if (ctrl == 0xE4) from = L;
-  else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int nsh = ctrl - 0x110; if ((L & 15) >= nsh) from = L - nsh; }
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int nsh = ctrl - 0x110; if ((L & 15) >= nsh) from = L - nsh; }
   else if (ctrl == 0x142) { if (r > 0) from = r * 16 - 1; }
   else if (ctrl == 0x143) { if (r >= 2) from = 31; }
   const int got = emu_exchange(src, from < 0 ? L : from);       // every lane takes part in the rendezvous
