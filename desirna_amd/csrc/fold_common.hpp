@@ -108,6 +108,13 @@ __device__ __forceinline__ f64x2 buf_load_f64x2(RS rsrc, int voff, int soff) {
   return f64x2{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
 }
 
+struct i32x4 { int x, y, z, w; };
+template <typename RS>
+__device__ __forceinline__ i32x4 buf_load_i32x4(RS rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+
 // ---- DPP wave reductions (no LDS traffic, fixed order => bit-reproducible)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {

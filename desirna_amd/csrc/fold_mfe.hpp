@@ -61,6 +61,10 @@ struct MfeSmem : MfeSmemCore<MAXN> {
   int pcnt[2];
   // interior-loop plan staged from HBM: u1 | u2 << 8 | kind << 16, and the size term
   int plan_u[NPLAN], plan_L[NPLAN];
+  // generic entries in slots of four consecutive ones (same loop size, consecutive u1): u1 | u2 << 8 of the first entry, and
+  // the four size terms (INF where the slot has fewer entries)
+  int plan_q[NPAIR_MAX];
+  i32x4 plan_qL[NPAIR_MAX];
 };
 
 // one wave: list of the cells (i, i+d) that can pair (hard constraints of the pseudoknot rounds included)
@@ -177,9 +181,16 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
     DML[3 * ld + k] = INF;
   }
   for (int e = tid; e < NPLAN; e += NT) { sm.plan_u[e] = P.u1[e] | (P.u2[e] << 8) | (P.kind[e] << 16); sm.plan_L[e] = P.L[e]; }
+  const int nquad = P.n_quad;
+  for (int p = tid; p < nquad; p += NT) {
+    const int e = P.quad_e[p], c = P.quad_n[p];
+    sm.plan_q[p] = P.u1[e] | (P.u2[e] << 8);
+    sm.plan_qL[p] = i32x4{P.L[e], c > 1 ? P.L[e + 1] : INF, c > 2 ? P.L[e + 2] : INF, c > 3 ? P.L[e + 3] : INF};
+  }
   if (wave == 0 && TURN + 1 < n) mfe_build_plist(sm, TURN + 1, n, lane);
   __syncthreads();
   const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)((long long)ld * ld * 4), 0x00020000);
+  const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)CI, (short)0, (int)((long long)ld * ld * 4), 0x00020000);
 
   for (int d = TURN + 1; d < n; d++) {
     const int ncell = n - d, par = d & 1;
@@ -245,23 +256,28 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
         }
         // generic interior loops: c + mismatchI(inner) precombined in CI, size term is a scalar
         int accG = INF;
-        for (int e = segG + h; e < NPLAN; e += 4 * HI) {
-          int pu[4], pl[4], v[4];
+        // (slots of four entries that sit in consecutive cells of one row of CI: one 16-byte load each)
+        for (int p = h; p < nquad; p += 4 * HI) {
+          int pu[4];
+          i32x4 pl[4], v[4];
           bool ok[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const int ee = as_vector(min(e + k * HI, NPLAN - 1));
-            pu[k] = sm.plan_u[ee]; pl[k] = sm.plan_L[ee];
+            const int pp = as_vector(min(p + k * HI, nquad - 1));
+            pu[k] = sm.plan_q[pp]; pl[k] = sm.plan_qL[pp];
           }
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
             const int dp = d - 2 - u1 - u2;
-            ok[k] = e + k * HI < NPLAN && dp > TURN;
-            v[k] = CI[ok[k] ? dp * ld + i + 1 + u1 : 0];
+            ok[k] = p + k * HI < nquad && dp > TURN;
+            v[k] = buf_load_i32x4(rsC, ok[k] ? (dp * ld + i + 1 + u1) * 4 : 0, 0);
           }
 #pragma unroll
-          for (int k = 0; k < 4; k++) accG = min(accG, ok[k] ? v[k] + pl[k] : INF);
+          for (int k = 0; k < 4; k++) {
+            const int m = min(min(v[k].x + pl[k].x, v[k].y + pl[k].y), min(v[k].z + pl[k].z, v[k].w + pl[k].w));
+            accG = min(accG, ok[k] ? m : INF);
+          }
         }
         accI = min(accI, accG + sm.mmI[ij]);
         sm.partI[item * WAVE + lane] = accI;
@@ -278,6 +294,15 @@ __device__ void mfe_fill(MfeSmem& sm, const MfeArgs& A, int32_t* __restrict__ Wc
         const int stepA = 4 * H * ld, stepC = 4 * H * (ld - 1);
         int vA = (tt * ld + i) * 4;
         int vC = ((d - tt - 1) * ld + i + tt + 1) * 4;                                     // operand of tt (never negative)
+        for (; tt + 7 * H <= d - TURN - 2; tt += 8 * H) {                                   // eight split points in flight
+          const int vCl = vC - 7 * stepC;                                                   // operand of tt + 7 H: in range here
+          int a[8], c[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { a[k] = buf_load_i32(rsF, vA, k * stepA); c[k] = buf_load_i32(rsF, vCl, (7 - k) * stepC); }
+          vA += 8 * stepA; vC -= 8 * stepC;
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) { acc0 = min(acc0, a[k] + c[k]); acc1 = min(acc1, a[k + 1] + c[k + 1]); }
+        }
         for (; tt + 3 * H <= d - TURN - 2; tt += 4 * H) {
           const int vCl = vC - 3 * stepC;                                                   // operand of tt + 3 H: in range here
           const int a0 = buf_load_i32(rsF, vA, 0), c0 = buf_load_i32(rsF, vCl, 3 * stepC);

@@ -49,6 +49,10 @@ struct PfSmem {
   // interior-loop plan staged from HBM: u1 | u2 << 8 | kind << 16, and the Boltzmann factor of the size term
   int plan_u[NPLAN];
   double plan_W[NPLAN];
+  // generic entries in slots of two consecutive ones (same loop size, consecutive u1): u1 | u2 << 8 | count << 16 of the
+  // first entry, and the two Boltzmann factors
+  int plan_p[NPAIR_MAX];
+  f64x2 plan_pW[NPAIR_MAX];
 };
 
 // one wave: list of the cells (i, i+d) that can pair
@@ -138,6 +142,12 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int e = tid; e < NPLAN; e += NT) { sm.plan_u[e] = P.u1[e] | (P.u2[e] << 8) | (P.kind[e] << 16); sm.plan_W[e] = P.W[e]; }
+  const int npair = P.n_pair;
+  for (int p = tid; p < npair; p += NT) {
+    const int e = P.pair_e[p], c = P.pair_n[p];
+    sm.plan_p[p] = P.u1[e] | (P.u2[e] << 8) | (c << 16);
+    sm.plan_pW[p] = f64x2{P.W[e], c > 1 ? P.W[e + 1] : 0.0};
+  }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
   const char* seq = A.seqs + (A.rg.off ? (long long)A.rg.off[r] : (long long)r * n);
@@ -164,7 +174,14 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   __syncthreads();
   // QM and QM1 (adjacent tables) through one buffer descriptor
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)QBI, (short)0, (int)(tab * 8), 0x00020000);
 
+#ifdef DRNA_PHASECLK
+  long long pc_t[6] = {0, 0, 0, 0, 0, 0}, pc_last = wall_clock64();
+#define PCLK(k) do { const long long _n = wall_clock64(); pc_t[k] += _n - pc_last; pc_last = _n; } while (0)
+#else
+#define PCLK(k) do { } while (0)
+#endif
   for (int d = TURN + 1; d < n; d++) {
     const int ncell = n - d, par = d & 1;
     const int nblk = (ncell + WAVE - 1) / WAVE;
@@ -230,27 +247,32 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
           }
         }
         double accG = 0.0;
-        for (int e = segG + h; e < NPLAN; e += 4 * HI) {
+        // (slots of two entries that sit in consecutive cells of one row of QBI: one 16-byte load each)
+        for (int p = h; p < npair; p += 4 * HI) {
           int pu[4];
-          double pw[4], v[4];
+          f64x2 pw[4], v[4];
           bool ok[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const int ee = as_vector(min(e + k * HI, NPLAN - 1));
-            pu[k] = sm.plan_u[ee]; pw[k] = sm.plan_W[ee];
+            const int pp = as_vector(min(p + k * HI, npair - 1));
+            pu[k] = sm.plan_p[pp]; pw[k] = sm.plan_pW[pp];
           }
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
             const int dp = d - 2 - u1 - u2;
-            ok[k] = e + k * HI < NPLAN && dp > TURN;
-            v[k] = QBI[ok[k] ? dp * ld + i + 1 + u1 : 0];
+            ok[k] = p + k * HI < npair && dp > TURN;
+            v[k] = buf_load_f64x2(rsB, ok[k] ? (dp * ld + i + 1 + u1) * 8 : 0, 0);
           }
 #pragma unroll
-          for (int k = 0; k < 4; k++) if (ok[k]) accG += v[k] * pw[k];
+          for (int k = 0; k < 4; k++) {
+            if (ok[k]) accG += v[k].x * pw[k].x;
+            if (ok[k] && (pu[k] >> 16) > 1) accG += v[k].y * pw[k].y;
+          }
         }
         accI += accG * sm.mmI[ij];
         sm.partI[item * WAVE + lane] = accI;
+        PCLK(0);
       } else {
         const int it = item - nI;
         const int b = it / H, h = it - b * H;
@@ -263,6 +285,15 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
         const int stepA = 8 * H * ld, stepC = 8 * H * (ld - 1);
         int vA = (tt * ld + i) * 8;
         int vC = (int)tab * 8 + ((d - tt - 1) * ld + i + tt + 1) * 8;                      // operand of tt (never negative)
+        for (; tt + 7 * H <= d - TURN - 2; tt += 8 * H) {                                   // eight split points in flight
+          const int vCl = vC - 7 * stepC;                                                   // operand of tt + 7 H: in range here
+          double a[8], c[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { a[k] = buf_load_f64(rsQ, vA, k * stepA); c[k] = buf_load_f64(rsQ, vCl, (7 - k) * stepC); }
+          vA += 8 * stepA; vC -= 8 * stepC;
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) { acc0 += a[k] * c[k]; acc1 += a[k + 1] * c[k + 1]; }   // same order as the 4-wide loop
+        }
         for (; tt + 3 * H <= d - TURN - 2; tt += 4 * H) {
           const int vCl = vC - 3 * stepC;                                                   // operand of tt + 3 H: in range here
           const double a0 = buf_load_f64(rsQ, vA, 0), c0 = buf_load_f64(rsQ, vCl, 3 * stepC);
@@ -277,9 +308,11 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
           vA += stepA; vC -= stepC;
         }
         sm.partK[it * WAVE + lane] = acc0 + acc1;
+        PCLK(1);
       }
     }
     __syncthreads();
+    PCLK(2);
 
     for (int i = tid + 1; i <= ncell; i += NT) {
       const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
@@ -313,9 +346,17 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
       DQ[at] = aK;
       QM[at] = m1 + aK + U;
     }
+    PCLK(3);
     if (wave == NW - 1 && d + 1 < n) pf_build_plist(sm, d + 1, n, lane);     // list of the next diagonal
+    PCLK(4);
     __syncthreads();
+    PCLK(5);
   }
+#ifdef DRNA_PHASECLK
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NW - 1 || wave == 5))
+    printf("pf_kernel wave %d: interior %lld K %lld barrierA %lld finalize %lld plist %lld barrierB %lld (100 MHz ticks)\n", wave,
+           pc_t[0], pc_t[1], pc_t[2], pc_t[3], pc_t[4], pc_t[5]);
+#endif
 
   // exterior: q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j)
   if (wave == 0) {

@@ -27,6 +27,7 @@ constexpr int INF_DEV = 1 << 22;    // device-side "infinity": (INF_DEV << 8) st
 constexpr int TURN = 3;
 constexpr int MAXLOOP = 30;
 constexpr int NPLAN = 496;          // #(u1,u2) with u1+u2 <= 30
+constexpr int NPAIR_MAX = 256;      // slots of consecutive generic entries (200 pairs / 109 quads with MAXLOOP = 30)
 constexpr int MAX_SPECIAL = 64;
 
 // plan kinds (wave-uniform switch in the fill kernels)
@@ -42,6 +43,12 @@ struct Plan {
   int seg[PK_NKINDS + 1];  // entries of kind k are [seg[k], seg[k+1])
   // canonical traceback order (p ascending, q descending): SURVEY App. A.4
   int tb_u1[NPLAN], tb_u2[NPLAN];
+  // The generic entries are ordered by (u1+u2, u1): entries of one loop size read CONSECUTIVE cells of one table row, so a
+  // lane can fetch them 16 bytes at a time.  Slots of two (fp64 tables) and of four (int32 tables) consecutive entries:
+  // first entry and number of entries (a slot never crosses a loop size).
+  int n_pair, n_quad;
+  int pair_e[NPAIR_MAX], pair_n[NPAIR_MAX];
+  int quad_e[NPAIR_MAX], quad_n[NPAIR_MAX];
 };
 
 struct MfeTables {
@@ -242,7 +249,11 @@ inline std::string build_tables(const int32_t* b, int n_int32, HostTables& T) {
     return (int)PK_GENERIC;
   };
   for (int u1 = 0; u1 <= MAXLOOP; u1++)
-    for (int u2 = 0; u1 + u2 <= MAXLOOP; u2++) order[kind_of(u1, u2)].push_back(u1 * 64 + u2);
+    for (int u2 = 0; u1 + u2 <= MAXLOOP; u2++)
+      if (kind_of(u1, u2) != PK_GENERIC) order[kind_of(u1, u2)].push_back(u1 * 64 + u2);
+  for (int sz = 0; sz <= MAXLOOP; sz++)           // generic entries by (size, u1)
+    for (int u1 = 0; u1 <= sz; u1++)
+      if (kind_of(u1, sz - u1) == PK_GENERIC) order[PK_GENERIC].push_back(u1 * 64 + (sz - u1));
   int e = 0;
   for (int k = 0; k < PK_NKINDS; k++) {
     P.seg[k] = e;
@@ -268,6 +279,14 @@ inline std::string build_tables(const int32_t* b, int n_int32, HostTables& T) {
     }
   }
   P.seg[PK_NKINDS] = e;
+  P.n_pair = P.n_quad = 0;
+  for (int g = P.seg[PK_GENERIC]; g < NPLAN;) {
+    int run = 1;                                 // entries of the same size with consecutive u1
+    while (g + run < NPLAN && P.u1[g + run] + P.u2[g + run] == P.u1[g] + P.u2[g] && P.u1[g + run] == P.u1[g] + run) run++;
+    for (int x = 0; x < run; x += 2) { P.pair_e[P.n_pair] = g + x; P.pair_n[P.n_pair] = std::min(2, run - x); P.n_pair++; }
+    for (int x = 0; x < run; x += 4) { P.quad_e[P.n_quad] = g + x; P.quad_n[P.n_quad] = std::min(4, run - x); P.n_quad++; }
+    g += run;
+  }
   e = 0;
   for (int u1 = 0; u1 <= MAXLOOP; u1++)       // p ascending
     for (int u2 = 0; u1 + u2 <= MAXLOOP; u2++) {  // q descending
