@@ -60,6 +60,8 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int segG = P.seg[PK_GENERIC];
+  int seg[PK_NKINDS];                   // first entry of every kind (wave-uniform: the kind of an entry stays scalar)
+  for (int k = 0; k < PK_NKINDS; k++) seg[k] = P.seg[k];
 
   double* base = A.ws + (long long)r * A.ws_stride;
   const long long tab = (long long)ld * ld;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
     sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
   }
   for (int k = tid; k <= n; k += NT) sm.q5[k] = q5g[k];
+  for (int e = tid; e < NPLAN; e += NT) { sm.plan_u[e] = P.u1[e] | (P.u2[e] << 8) | (P.kind[e] << 16); sm.plan_W[e] = P.W[e]; }
   __syncthreads();
   if (tid == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
   __syncthreads();
@@ -136,38 +139,66 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
         const int info = INFO[d * ld + i];
         const int t2 = info >> 4;                 // rtype of (i,j) seen as the inner pair
         double accI = 0.0;
-        for (int e = h; e < segG; e += HI) {
-          const int u1 = P.u1[e], u2 = P.u2[e];
-          const bool ok = i - 1 - u1 >= 1 && j + 1 + u2 <= n;
-          const int io = ok ? i - 1 - u1 : 1, jo = ok ? j + 1 + u2 : n;
-          const double o = OB[(jo - io) * ld + io];
-          const int t = pair_type(sm.S[io], sm.S[jo]);
-          const int si1 = sm.S[io + 1], sj1 = sm.S[jo - 1];
-          const int ij = t * 16 + si1 * 4 + sj1;
-          const double tau = t > 2 ? T.TermAU : 1.0;
-          double f;
-          switch (P.kind[e]) {
-            case PK_STACK: f = sm.stack[t * 8 + t2]; break;
-            case PK_BULGE1: f = sm.stack[t * 8 + t2]; break;
-            case PK_BULGEN: f = tau * (t2 > 2 ? T.TermAU : 1.0); break;
-            case PK_INT11: f = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
-            case PK_INT21: f = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
-            case PK_INT12: f = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
-            case PK_1XN: f = sm.mm1n[ij] * sm.mm1n[info]; break;
-            case PK_INT22:
-              f = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
-              break;
-            default: /* PK_INT23 */ f = sm.mm23[ij] * sm.mm23[info]; break;
+        // four plan entries per pass in explicit stages (entries from LDS, the four table loads, the arithmetic), as in pf_kernel
+        for (int e = h; e < segG; e += 4 * HI) {
+          int pu[4], io4[4], jo4[4];
+          double pw[4], o4[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int ee = as_vector(min(e + k * HI, segG - 1));
+            pu[k] = sm.plan_u[ee]; pw[k] = sm.plan_W[ee];
           }
-          if (ok) accI += o * f * P.W[e];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            ok[k] = e + k * HI < segG && i - 1 - u1 >= 1 && j + 1 + u2 <= n;
+            io4[k] = ok[k] ? i - 1 - u1 : 1; jo4[k] = ok[k] ? j + 1 + u2 : n;
+            o4[k] = OB[(jo4[k] - io4[k]) * ld + io4[k]];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int io = io4[k], jo = jo4[k];
+            const int t = pair_type(sm.S[io], sm.S[jo]);
+            const int si1 = sm.S[io + 1], sj1 = sm.S[jo - 1];
+            const int ij = t * 16 + si1 * 4 + sj1;
+            const double tau = t > 2 ? T.TermAU : 1.0;
+            double f;
+            switch (plan_kind(seg, e + k * HI)) {
+              case PK_STACK: f = sm.stack[t * 8 + t2]; break;
+              case PK_BULGE1: f = sm.stack[t * 8 + t2]; break;
+              case PK_BULGEN: f = tau * (t2 > 2 ? T.TermAU : 1.0); break;
+              case PK_INT11: f = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1]; break;
+              case PK_INT21: f = T.int21[(t * 8 + t2) * 64 + si1 * 16 + ((info >> 2) & 3) * 4 + sj1]; break;
+              case PK_INT12: f = T.int21[(t2 * 8 + t) * 64 + ((info >> 2) & 3) * 16 + si1 * 4 + (info & 3)]; break;
+              case PK_1XN: f = sm.mm1n[ij] * sm.mm1n[info]; break;
+              case PK_INT22:
+                f = T.int22[(t * 8 + t2) * 256 + si1 * 64 + (info & 3) * 16 + ((info >> 2) & 3) * 4 + sj1];
+                break;
+              default: /* PK_INT23 */ f = sm.mm23[ij] * sm.mm23[info]; break;
+            }
+            if (ok[k]) accI += o4[k] * f * pw[k];
+          }
         }
         double accG = 0.0;
-        for (int e = segG + h; e < NPLAN; e += HI) {
-          const int u1 = P.u1[e], u2 = P.u2[e];
-          const bool ok = i - 1 - u1 >= 1 && j + 1 + u2 <= n;
-          const int io = ok ? i - 1 - u1 : 1, jo = ok ? j + 1 + u2 : n;
-          const double o = OBI[(jo - io) * ld + io];
-          if (ok) accG += o * P.W[e];
+        for (int e = segG + h; e < NPLAN; e += 8 * HI) {
+          int pu[8];
+          double pw[8], o8[8];
+          bool ok[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int ee = as_vector(min(e + k * HI, NPLAN - 1));
+            pu[k] = sm.plan_u[ee]; pw[k] = sm.plan_W[ee];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int u1 = pu[k] & 255, u2 = (pu[k] >> 8) & 255;
+            ok[k] = e + k * HI < NPLAN && i - 1 - u1 >= 1 && j + 1 + u2 <= n;
+            const int io = ok[k] ? i - 1 - u1 : 1, jo = ok[k] ? j + 1 + u2 : n;
+            o8[k] = OBI[(jo - io) * ld + io];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (ok[k]) accG += o8[k] * pw[k];
         }
         accI += accG * sm.mmI[info];
         sm.partI[item * WAVE + lane] = accI;
@@ -181,11 +212,27 @@ __global__ __launch_bounds__(NT) void outside_kernel(OutArgs A) {
         // Om[i,j] = sum_s A[i, j+1+s] qm1[j+1, j+1+s]
         double accA1 = 0.0;
         const int smax = act ? n - j - 1 : -1;
-        for (int s = TURN + 1 + h; s <= smax; s += H) accA1 += AT[(d + 1 + s) * ld + i] * QM1[s * ld + j + 1];
+        int s = TURN + 1 + h;
+        for (; s + 3 * H <= smax; s += 4 * H) {                 // four terms in flight, summed in the order of the plain loop
+          double a[4], c[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { a[k] = AT[(d + 1 + s + k * H) * ld + i]; c[k] = QM1[(s + k * H) * ld + j + 1]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) accA1 += a[k] * c[k];
+        }
+        for (; s <= smax; s += H) accA1 += AT[(d + 1 + s) * ld + i] * QM1[s * ld + j + 1];
         // sum_t A[i-t, j] qm[i-t, i-1]
         double accA2 = 0.0;
         const int tmax = act ? i - 1 : -1;
-        for (int t = TURN + 2 + h; t <= tmax; t += H) accA2 += AT[(d + t) * ld + i - t] * QM[(t - 1) * ld + i - t];
+        int t = TURN + 2 + h;
+        for (; t + 3 * H <= tmax; t += 4 * H) {
+          double a[4], c[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { a[k] = AT[(d + t + k * H) * ld + i - t - k * H]; c[k] = QM[(t + k * H - 1) * ld + i - t - k * H]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) accA2 += a[k] * c[k];
+        }
+        for (; t <= tmax; t += H) accA2 += AT[(d + t) * ld + i - t] * QM[(t - 1) * ld + i - t];
         sm.partK[it * WAVE + lane] = accA1;
         sm.partM[it * WAVE + lane] = accA2;
       }
