@@ -484,9 +484,16 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
       if (lane == 0) { sm.ssw[i - 1] = '('; sm.ssw[j - 1] = ')'; }
       const int d = j - i;
       const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+      // (i,j) and the pair stacked on it are fetched together: along a helix the stack is the first interior candidate in
+      // ViennaRNA's order, so one L2 round trip settles the step instead of three (cell, plan words, inner cells)
+      const int w_in = d - 2 > TURN ? Wc[(d - 2) * ld + i + 1] : INF_DEV * 256;
       const int cij = Wc[d * ld + i] >> 8;
       if (cij == mfe_hairpin(sm, A, i, j, t)) break;
       const int si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+      if ((w_in >> 8) < HALF && cij == (w_in >> 8) + mfe_intloop(sm, T, 0, 0, t, si1, sj1, w_in & 127)) {
+        i++; j--;
+        continue;
+      }
       int found = -1;
       for (int base = 0; base < NPLAN && found < 0; base += WAVE) {
         const int k = base + lane;

@@ -550,9 +550,19 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   int status = ST_OK;
   for (int round = 0; round <= A.pk_rounds; round++) {
     for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
+#ifdef DRNA_PHASECLK
+    const long long pc0 = wall_clock64();
+#endif
     mfe_fill_lds<NT>(sm, A, Wc, EXT, PL);           // ends with a barrier
+#ifdef DRNA_PHASECLK
+    const long long pc1 = wall_clock64();
+#endif
     if (wave_id() == 0) {
-      const bool ok = mfe_traceback(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT);
+      const bool ok = (DRNA_SKIP & 256) ? true : mfe_traceback(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT);
+#ifdef DRNA_PHASECLK
+      if (blockIdx.x == 0 && lane_id() == 0)
+        printf("mfe_lds_kernel: fill %lld traceback %lld (100 MHz ticks)\n", pc1 - pc0, wall_clock64() - pc1);
+#endif
       if (lane_id() == 0) {
         if (round == 0) A.Emfe[r] = sm.f5[n];
         sm.flag = ok ? 0 : 1;

@@ -297,7 +297,8 @@ inline std::string build_tables(const int32_t* b, int n_int32, HostTables& T) {
 
 inline void size_tables(HostTables& T, int max_L) {
   const double kT = T.pf.kT;
-  int N = max_L + 4;
+  // the loop-size weights scale[u1+u2+2] are tabulated for every loop size up to MAXLOOP whatever the sequence length
+  int N = (max_L > MAXLOOP + 4 ? max_L : MAXLOOP + 4) + 4;
   T.hp_len.assign(N, INF_DEV);
   T.hp_w.assign(N, 0.0);
   T.scale.assign(N, 1.0);

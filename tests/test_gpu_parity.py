@@ -389,6 +389,25 @@ def test_subopt_energy_vs_oracle(eng400, oracle):
             assert int(E12[k, 0]) == oracle.mfe(s)[1]
 
 
+def test_small_engines(oracle):
+    """engines sized exactly for short sequences (BASELINE config 1: L=16, R=4): the loop-size tables must not depend on max_L"""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(16)
+    for L, R in ((16, 4), (9, 2), (5, 1)):
+        eng = E.Engine(max_R=R, max_L=L, device=0)
+        tg = "(((((......)))))" if L == 16 else "." * L
+        eng.set_targets([tg])
+        for rep in range(3):
+            seqs = [_rand(rng, L, "GC" if k % 2 else "ACGU") for k in range(R)]
+            out = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+            for k, s in enumerate(seqs):
+                ss, e = oracle.mfe(s)
+                assert out["mfe_ss"][k] == ss and int(out["Emfe"][k]) == e, s
+                assert abs(float(out["Epf"][k]) - oracle.pf(s)) < 1e-9, s
+                assert int(out["Ed"][k, 0]) == oracle.eval_structure(s, tg), s
+        eng.close()
+
+
 def test_maximum_length(oracle):
     """the engine's length limit (MAXN - 2 = 2046 nt, general kernels): same bits as the oracle"""
     from desirna_amd import engine as E

@@ -17,3 +17,11 @@ eng.set_targets([tg])
 for _ in range(2):
     eng.score_batch(seqs, E.NEED_PF)
 print(eng.last_timing())
+
+# LDS-resident MFE kernel (L=200): fill / traceback split of block 0
+tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = 64
+seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
+eng2 = E.Engine(max_R=R, max_L=L, lib=out)
+eng2.set_targets([tg])
+eng2.score_batch(seqs, E.NEED_MFE)
+print(eng2.last_timing())
