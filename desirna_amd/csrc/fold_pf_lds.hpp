@@ -15,6 +15,9 @@
 //     diagonal.  Every partial sum has exactly one writer and is combined in a fixed order, so the
 //     result is bit-reproducible from run to run and independent of the batch composition.
 #pragma once
+#ifndef DRNA_JOIN_MASK
+#define DRNA_JOIN_MASK 0xF     // finalize waves that join the sweep's work queue once their own step is done
+#endif
 #include "fold_pf.hpp"
 
 namespace drna {
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       }
       if (!(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
       STAMP(4);
-      if (!(DRNA_SKIP & 128) && k < n) run_items(k);          // help the sweep of diagonal k
+      if (!(DRNA_SKIP & 128) && k < n && ((DRNA_JOIN_MASK >> wave) & 1)) run_items(k);          // help the sweep of diagonal k
       __syncthreads();
       STAMP(3);
 #ifdef DRNA_STAMPS
