@@ -395,6 +395,29 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
   const int HALF = INF_DEV / 2;
   int sp = 0;
   bool ok = true;
+  // The interior scan gives lane l of round r the candidate k = 64 r + l of the canonical order.  Its shape, its kind and its
+  // size term (what E_IntLoop adds for the loop size and asymmetry) are fixed for the whole traceback: fetched and computed
+  // once, kept in registers, so that a scan round is LDS lookups plus at most one global load (2x1 / 1x2 / 2x2 lanes).
+  constexpr int NRND = (NPLAN + WAVE - 1) / WAVE;
+  int tb_shape[NRND], tb_L[NRND];
+#pragma unroll
+  for (int rnd = 0; rnd < NRND; rnd++) {
+    const int k = rnd * WAVE + lane;
+    int u1 = 0, u2 = 0;
+    if (k < NPLAN) { u1 = P.tb_u1[k]; u2 = P.tb_u2[k]; }
+    const int nl = u1 > u2 ? u1 : u2, ns = u1 > u2 ? u2 : u1;
+    int kind, L = 0;
+    if (nl == 0) kind = PK_STACK;
+    else if (ns == 0) { kind = nl == 1 ? PK_BULGE1 : PK_BULGEN; L = T.bulge[nl]; }
+    else if (ns == 1 && nl == 1) kind = PK_INT11;
+    else if (ns == 1 && nl == 2) kind = u1 == 1 ? PK_INT21 : PK_INT12;
+    else if (ns == 1) { kind = PK_1XN; L = T.interior[nl + 1] + min(T.max_ninio, (nl - ns) * T.ninio); }
+    else if (ns == 2 && nl == 2) kind = PK_INT22;
+    else if (ns == 2 && nl == 3) { kind = PK_INT23; L = T.interior[5] + T.ninio; }
+    else { kind = PK_GENERIC; L = T.interior[nl + ns] + min(T.max_ninio, (nl - ns) * T.ninio); }
+    tb_shape[rnd] = u1 | (u2 << 8) | (kind << 16);
+    tb_L[rnd] = L;
+  }
   // sector stack lives in LDS; every lane keeps the same sp
   sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 0; sp = 1;
   while (sp > 0 && ok) {
@@ -495,20 +518,29 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
         continue;
       }
       int found = -1;
-      for (int base = 0; base < NPLAN && found < 0; base += WAVE) {
-        const int k = base + lane;
-        bool hit = false;
-        if (k < NPLAN) {
-          const int u1 = P.tb_u1[k], u2 = P.tb_u2[k];
-          const int dp = d - 2 - u1 - u2;
-          if (dp > TURN) {
-            const int w = Wc[dp * ld + i + 1 + u1];
-            const int cpq = w >> 8;
-            if (cpq < HALF) hit = cij == cpq + mfe_intloop(sm, T, u1, u2, t, si1, sj1, w & 127);
-          }
-        }
+      const int tij = t * 16 + si1 * 4 + sj1, tauI = t > 2 ? T.TermAU : 0;
+#pragma unroll
+      for (int rnd = 0; rnd < NRND; rnd++) {
+        if (found >= 0) break;
+        const int k = rnd * WAVE + lane;
+        const int u1 = tb_shape[rnd] & 255, u2 = (tb_shape[rnd] >> 8) & 255, kind = tb_shape[rnd] >> 16;
+        const int dp = d - 2 - u1 - u2;
+        const bool live = k < NPLAN && dp > TURN;
+        const int w = live ? Wc[dp * ld + i + 1 + u1] : INF_DEV * 256;
+        const int cpq = w >> 8, info = w & 127, t2 = info >> 4, sq1 = (info >> 2) & 3, sp1 = info & 3;
+        // the mismatch-pair kinds share one code path through the table of their kind (mm1n, mm23, mmI: LDS)
+        const int* mm = kind == PK_1XN ? sm.mm1n : kind == PK_INT23 ? sm.mm23 : sm.mmI;
+        int en = mm[tij] + mm[info];
+        const int e_stack = sm.stack[t * 8 + t2], e_11 = sm.int11[(t * 8 + t2) * 16 + si1 * 4 + sj1];
+        en = kind == PK_STACK || kind == PK_BULGE1 ? e_stack : en;
+        en = kind == PK_BULGEN ? tauI + (t2 > 2 ? T.TermAU : 0) : en;
+        en = kind == PK_INT11 ? e_11 : en;
+        if (kind == PK_INT21) en = T.int21[(t * 8 + t2) * 64 + si1 * 16 + sq1 * 4 + sj1];
+        else if (kind == PK_INT12) en = T.int21[(t2 * 8 + t) * 64 + sq1 * 16 + si1 * 4 + sp1];
+        else if (kind == PK_INT22) en = T.int22[(t * 8 + t2) * 256 + si1 * 64 + sp1 * 16 + sq1 * 4 + sj1];
+        const bool hit = live && cpq < HALF && cij == cpq + en + tb_L[rnd];
         const int fl = first_lane(__ballot(hit));
-        if (fl >= 0) found = base + fl;
+        if (fl >= 0) found = rnd * WAVE + fl;
       }
       if (found >= 0) {
         i = i + 1 + P.tb_u1[found];
