@@ -382,7 +382,7 @@ static int eval_loop(const evalctx *E, int i, int j) {
 }
 
 static int *encode_seq(const char *seq, int n) {
-  int *S = (int *)malloc(sizeof(int) * (size_t)(n + 2));
+  int *S = (int *)calloc((size_t)n + 2, sizeof(int));
   for (int i = 1; i <= n; i++) S[i] = enc(seq[i - 1]);
   S[0] = S[n];
   S[n + 1] = S[1];
@@ -862,7 +862,8 @@ double orc_pf(const orc_params *P, const char *seq, int n) {
 
 /* Outside recursion -> base-pair probabilities -> ensemble defect (reference
  * energy_scores.py:362-374; ViennaRNA vrna_ensemble_defect).  NOT golden-pinned (no vector in the
- * reference); validated in tests by exhaustive enumeration on short sequences. */
+ * reference); Z, every P(i,j) and the defect are checked against the explicit sum over ALL structures weighted by
+ * orc_boltzmann_weight (tests/test_oracle_golden.py::test_pf_bpp_defect_against_enumeration). */
 double orc_ensemble_defect(const orc_params *P, const char *seq, int n, const char *target, double *bpp) {
   pfctx F;
   pf_fill(P, &F, seq, n);
@@ -963,6 +964,69 @@ double orc_ensemble_defect(const orc_params *P, const char *seq, int n, const ch
   free(Ob); free(Om); free(Om1); free(q3); free(pt); free(stk); free(pi);
   pf_free(&F);
   return ed;
+}
+
+/* Boltzmann weight of ONE structure under the partition function's loop model (the X_* factors with pf_smooth,
+ * untruncated log extrapolation; no pf_scale): exp(-E_pf(seq, db) / kT).  A structure walk, independent of pf_fill and
+ * of the outside recursion, so that Z, the pair probabilities and the ensemble defect can be checked against an explicit
+ * sum over all structures (tests/test_oracle_golden.py).  Only '(' ')' pair; pairs must be canonical (0 otherwise). */
+static double weight_loop(const orc_params *P, const int *S, const int *pt, const char *up, int i, int j) {
+  int t = PAIR[S[i]][S[j]];
+  if (!t) return 0.0;
+  int nstems = 0, unpaired = 0, fp = 0, fq = 0;
+  for (int p = i + 1; p < j;) {
+    if (pt[p] > p) { if (!nstems) { fp = p; fq = pt[p]; } nstems++; p = pt[p] + 1; }
+    else { unpaired++; p++; }
+  }
+  if (nstems == 0) return X_Hairpin(P, j - i - 1, t, S[i + 1], S[j - 1], up + i - 1);
+  if (nstems == 1) {
+    int t2 = PAIR[S[fp]][S[fq]];
+    if (!t2) return 0.0;
+    return X_IntLoop(P, fp - i - 1, j - fq - 1, t, RTYPE[t2], S[i + 1], S[j - 1], S[fp - 1], S[fq + 1]) *
+           weight_loop(P, S, pt, up, fp, fq);
+  }
+  double w = P->eMLclosing * X_MLstem(P, RTYPE[t], S[j - 1], S[i + 1]);
+  for (int k = 0; k < unpaired; k++) w *= P->eMLbase;
+  for (int p = i + 1; p < j;) {
+    if (pt[p] > p) {
+      int q = pt[p], t2 = PAIR[S[p]][S[q]];
+      if (!t2) return 0.0;
+      w *= X_MLstem(P, t2, S[p - 1], S[q + 1]) * weight_loop(P, S, pt, up, p, q);
+      p = q + 1;
+    } else p++;
+  }
+  return w;
+}
+
+double orc_boltzmann_weight(const orc_params *P, const char *seq, const char *db, int n) {
+  int *S = encode_seq(seq, n);
+  int *pt = (int *)calloc((size_t)n + 2, sizeof(int));
+  int *stk = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+  char *up = (char *)malloc((size_t)n + 1);
+  int sp = 0, bad = 0;
+  for (int i = 0; i < n; i++) {
+    char ch = seq[i];
+    ch = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch;
+    up[i] = (ch == 'T') ? 'U' : ch;
+  }
+  up[n] = 0;
+  for (int i = 1; i <= n && !bad; i++) {
+    if (db[i - 1] == '(') stk[sp++] = i;
+    else if (db[i - 1] == ')') {
+      if (!sp) bad = 1;
+      else { int o = stk[--sp]; pt[o] = i; pt[i] = o; }
+    }
+  }
+  double w = (bad || sp) ? 0.0 : 1.0;
+  for (int i = 1; i <= n && w != 0.0;) {
+    if (pt[i] > i) {
+      int j = pt[i], t = PAIR[S[i]][S[j]];
+      w *= t ? X_ExtLoop(P, t, i > 1 ? S[i - 1] : -1, j < n ? S[j + 1] : -1) * weight_loop(P, S, pt, up, i, j) : 0.0;
+      i = j + 1;
+    } else i++;
+  }
+  free(S); free(pt); free(stk); free(up);
+  return w;
 }
 
 /* ---------------------------------------------------------------- SimScore, reference utils/sim_score.py */

@@ -15,7 +15,8 @@
  * structures, pk-annotated structures, 1-MCC/recall/precision) and
  * eterna_benchmark/Eterna100V1_benchmark_results (MFE(sequence) == structure).  See
  * tests/golden/ and tests/test_oracle_golden.py.  Outside recursion / ensemble defect has no
- * golden vector in the reference ("parity unpinned" for that one quantity).
+ * golden vector in the reference ("parity unpinned" for that one quantity); it is verified against
+ * an explicit Boltzmann-weighted sum over all structures of short sequences instead.
  *
  * Model in force (reference energy_scores.py:27-28 sets only compute_bpp=0): 37 degC, dangles=2,
  * noLP=0, noGU=0, special hairpins on, TURN=3, MAXLOOP=30, linear, no G-quadruplexes,
@@ -55,6 +56,10 @@ void orc_pk_struct(const orc_params *P, const char *seq, int n, const char *ss_n
 /* fc.ensemble_defect(target) after mfe/rescale/pf with bpp on; bpp (may be NULL) gets the
  * (n+1)*(n+1) base-pair probability matrix, 1-based, upper triangle */
 double orc_ensemble_defect(const orc_params *P, const char *seq, int n, const char *target, double *bpp);
+
+/* exp(-E/kT) of ONE structure under the partition function's loop model (pf_smooth dangles, no pf_scale); a structure
+ * walk independent of the DP, used by the tests to check Z, P(i,j) and the defect against explicit enumeration */
+double orc_boltzmann_weight(const orc_params *P, const char *seq, const char *db, int n);
 
 /* SimScore(ref, query): out[0]=mcc, out[1]=recall, out[2]=precision, each round(x,3) (NOT 1-x);
  * conf (may be NULL) gets tp, fp, fn, tn */

@@ -103,6 +103,12 @@ class Oracle:
                                          bpp.ctypes.data if want_bpp else None)
         return (ed, bpp) if want_bpp else ed
 
+    def boltzmann_weight(self, seq, db):
+        """exp(-E/kT) of one structure under the partition function's loop model (no pf_scale)"""
+        self._L.orc_boltzmann_weight.restype = C.c_double
+        self._L.orc_boltzmann_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+        return self._L.orc_boltzmann_weight(self._P, seq.encode(), db.encode(), len(seq))
+
     def cofold_mfe(self, seq_with_amp):
         """fc.mfe_dimer(): (structure with '&' re-inserted, energy in dcal/mol)"""
         a, b = seq_with_amp.split("&")

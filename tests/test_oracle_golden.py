@@ -140,19 +140,75 @@ def _enumerate(seq, oracle):
     return out
 
 
-def test_pf_and_bpp_against_enumeration(oracle):
-    """Not pinned by the reference (no golden for bpp / ensemble defect): check the recursions
-    against explicit enumeration of all structures, with Boltzmann weights from the INTEGER loop
-    model (pf_smooth off for that comparison is not available, so compare bpp-derived quantities
-    only through self-consistency: sum_j P_ij <= 1, defect of MFE structure in [0,1])."""
+KT = (37.0 + 273.15) * 1.98717 / 1000.0      # kcal/mol, SURVEY App. A.5
+
+# hand-picked cases on top of the random ones: two hairpins inside a closing pair (multiloop), 1xn and 2x3 interior loops
+ENUM_FIXED = [
+    ("GGGAAACGGAAACCGAAACC", None),          # n=20: multiloop with two stems is among the structures
+    ("GCGAAAGCGCAAAGCGC", None),
+    ("GGACGAAAGCAAAACC", "((.(....)....))"),  # 1x4 interior loop as the defect target
+    ("GGAACGAAAGAAACC", "((..(....)...))"),  # 2x3 interior loop as the defect target
+    ("GCAAGCAAAGCAAAAGC", "(...(....)....)"), # 3x4 generic interior loop
+]
+
+
+def _pairs_of(db):
+    st, out = [], []
+    for k, ch in enumerate(db):
+        if ch == "(":
+            st.append(k)
+        elif ch == ")":
+            out.append((st.pop(), k))
+    return out
+
+
+def test_pf_bpp_defect_against_enumeration(oracle):
+    """The reference holds no golden for base-pair probabilities / ensemble defect (utils/energy_scores.py:362-374), so
+    the oracle's inside AND outside recursions are checked against the definition: every secondary structure of a short
+    sequence is enumerated, weighted with the partition function's own loop model (orc_boltzmann_weight: an independent
+    structure walk, pf_smooth included), and Z = sum w, P(i,j) = sum_{s contains (i,j)} w / Z and the defect
+    (1/n) [sum_{i unpaired in target} sum_j P_ij + sum_{(i,j) in target} 2 (1 - P_ij)] are compared to 1e-12."""
     rng = np.random.default_rng(5)
-    for _ in range(5):
-        seq = "".join(rng.choice(list("ACGU"), 14))
-        ss, _ = oracle.mfe(seq)
-        ed, bpp = oracle.ensemble_defect(seq, ss, want_bpp=True)
-        assert 0.0 <= ed <= 1.0
-        p = bpp + bpp.T
-        assert (p.sum(axis=1) <= 1 + 1e-9).all()
+    cases = list(ENUM_FIXED)
+    for trial in range(32):
+        L = int(rng.integers(10, 19))
+        cases.append(("".join(rng.choice(list("ACGU" if trial % 3 else "GC"), L)), None))
+    n_multi = n_1xn = n_2x3 = 0
+    for seq, target in cases:
+        n = len(seq)
+        structs = _enumerate(seq, oracle)
+        w = np.array([oracle.boltzmann_weight(seq, st) for st in structs])
+        assert (w > 0).all()
+        Z = w.sum()
+        assert abs(-KT * np.log(Z) - oracle.pf(seq)) < 1e-11, seq
+        P = np.zeros((n, n))
+        for st, wi in zip(structs, w):
+            prs = _pairs_of(st)
+            for (i, j) in prs:
+                P[i, j] += wi
+            # census of loop kinds seen, so the test cannot silently degenerate to hairpin-only ensembles
+            for (i, j) in prs:
+                inner = [(p, q) for (p, q) in prs if i < p and q < j and not any(i < a < p and q < b < j for (a, b) in prs)]
+                if len(inner) >= 2:
+                    n_multi += 1
+                elif len(inner) == 1:
+                    u = sorted((inner[0][0] - i - 1, j - inner[0][1] - 1))
+                    n_1xn += u[0] == 1 and u[1] >= 3
+                    n_2x3 += u == [2, 3]
+        P /= Z
+        tgt = target or structs[int(np.argmax(w))]
+        ed, bpp = oracle.ensemble_defect(seq, tgt, want_bpp=True)
+        assert np.abs(bpp[1:, 1:] - P).max() < 1e-12, seq
+        pi = P.sum(axis=0) + P.sum(axis=1)
+        paired = {}
+        for (i, j) in _pairs_of(tgt):
+            paired[i], paired[j] = (i, j), (i, j)
+        want = sum((1.0 - P[paired[k]]) if k in paired else pi[k] for k in range(n)) / n
+        assert abs(ed - want) < 1e-12, (seq, tgt)
+        # a target that is NOT the most probable structure: the open chain
+        ed0 = oracle.ensemble_defect(seq, "." * n)
+        assert abs(ed0 - pi.sum() / n) < 1e-12
+    assert n_multi > 0 and n_1xn > 0 and n_2x3 > 0
 
 
 # ---- two strands: co-fold MFE and partition function (SURVEY 8(f)-2), pinned on the reference's two-strand trajectories
