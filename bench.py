@@ -126,10 +126,9 @@ def cpu_baseline(seqs, target, budget_s=25.0):
     single, allc = table[0]["folds_per_s"], table[-1]["folds_per_s"]
     return {"value": allc, "unit": "replica-folds/s", "cores": cores, "kind": "port",
             "sample": "%d x L=%d sequences (the benchmark batch tiled to 8 folds per thread), best of 3 after one warm-up, %d "
-                      "threads = usable cores (affinity %d, cgroup quota %s, os.cpu_count %d), OMP_PROC_BIND=%s; "
-                      "MFE fill+traceback + PF + eval each" % (table[-1]["folds"], len(seqs[0]), cores,
-                                                              len(os.sched_getaffinity(0)), quota, os.cpu_count() or 0,
-                                                              os.environ.get("OMP_PROC_BIND")),
+                      "threads = usable cores (affinity %d, cgroup quota %s, os.cpu_count %d), thread t bound to the t-th "
+                      "CPU of the affinity mask; MFE fill+traceback + PF + eval each"
+                      % (table[-1]["folds"], len(seqs[0]), cores, len(os.sched_getaffinity(0)), quota, os.cpu_count() or 0),
             "single_core_value": single, "effective_cores": allc / single, "scaling_table": table}, ref
 
 
@@ -192,8 +191,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    os.environ.setdefault("OMP_PROC_BIND", "close")        # cpu_baseline leg: bind the oracle's OpenMP threads
-    os.environ.setdefault("OMP_PLACES", "cores")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -897,12 +897,24 @@ extern "C" int drna_simscore_batch(int R, int L, const char* ref, const char* qu
   return DRNA_OK;
 }
 
+extern "C" int drna_rng_seed(int R, const uint64_t* seeds, uint32_t* rng_state) {
+  if (R < 0 || (R > 0 && (!seeds || !rng_state))) return DRNA_ERR_ARG;
+  for (int r = 0; r < R; r++) drna_host::mt_seed_int(drna_host::Mt{rng_state + (size_t)r * drna_host::RNG_WORDS}, seeds[r]);
+  return DRNA_OK;
+}
+
+extern "C" int drna_rng_random(int R, uint32_t* rng_state, double* out) {
+  if (R < 0 || (R > 0 && (!rng_state || !out))) return DRNA_ERR_ARG;
+  for (int r = 0; r < R; r++) out[r] = drna_host::rnd01(drna_host::Mt{rng_state + (size_t)r * drna_host::RNG_WORDS});
+  return DRNA_OK;
+}
+
 // one proposal per replica; pt_design = partner of every design pair (target + ordinary alternative pairs), snakes optional
 static int propose_impl(int R, int L, const char* target, const int32_t* partner, const unsigned char* allowed_mask,
                         const int32_t* snake_of, const int32_t* snake_off, const int32_t* snake_nodes,
                         const int32_t* snake_nstates, const char* snake_states, const char* seqs, const char* mfe_ss,
                         const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
-                        uint64_t* rng_state, char* out_seqs) {
+                        uint32_t* rng_state, char* out_seqs) {
   using namespace drna_host;
   static const char LET[4] = {'A', 'C', 'G', 'U'};
   static const unsigned CANPAIR[4] = {8u, 4u, 2u | 8u, 1u | 4u};   // A-U, C-G, G-C/U, U-A/G
@@ -918,7 +930,7 @@ static int propose_impl(int R, int L, const char* target, const int32_t* partner
   if (mutable_pos.empty()) return DRNA_ERR_ARG;
   auto letter_index = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
   for (int r = 0; r < R; r++) {
-    uint64_t& st = rng_state[r];
+    const Mt st{rng_state + (size_t)r * RNG_WORDS};
     const char* s = seqs + (size_t)r * L;
     char* o = out_seqs + (size_t)r * L;
     std::memcpy(o, s, (size_t)L);
@@ -933,9 +945,15 @@ static int propose_impl(int R, int L, const char* target, const int32_t* partner
           for (int k = -3; k <= 3; k++) { const int x = i + k; if (x > 0 && x <= L - 1) mark[x] = 1; }
         }
       if (any) {
-        double p = n_shelves > 1 ? tm_max + (tm_min - tm_max) * (double)shelf_index[r] / (double)(n_shelves - 1) : tm_max;
+        // round(numpy.linspace(tm_max, tm_min, n_shelves)[shelf], 2): linspace is start + k * step with the last point
+        // set to the stop value; round() is the correctly rounded decimal, like printf
+        double p = tm_max;
+        if (n_shelves > 1) {
+          const double step = (tm_min - tm_max) / (double)(n_shelves - 1);
+          p = shelf_index[r] == n_shelves - 1 ? tm_min : (double)shelf_index[r] * step + tm_max;
+        }
         char buf[32]; snprintf(buf, sizeof buf, "%.2f", p); p = strtod(buf, nullptr);
-        if (rnd01(st) < p) {
+        if (rnd_choices2(st, p) == 0) {                      // choices([expanded, mutable], weights=[p, 1 - p])
           pool.clear();
           for (int i = 0; i < L; i++) if (mark[i]) pool.push_back(i);
           pos = pool[rnd_below(st, (int)pool.size())];
@@ -986,7 +1004,7 @@ static int propose_impl(int R, int L, const char* target, const int32_t* partner
 
 extern "C" int drna_propose_batch(int R, int L, const char* target, const unsigned char* allowed_mask, const char* seqs,
                                   const char* mfe_ss, const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min,
-                                  int targeted, uint64_t* rng_state, char* out_seqs) {
+                                  int targeted, uint32_t* rng_state, char* out_seqs) {
   if (R < 0 || L < 1 || L > 2048 || !target || !allowed_mask || (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
     return DRNA_ERR_ARG;
   return propose_impl(R, L, target, nullptr, allowed_mask, nullptr, nullptr, nullptr, nullptr, nullptr, seqs, mfe_ss,
@@ -998,7 +1016,7 @@ extern "C" int drna_propose_batch_alt(int R, int L, const char* target, const in
                                       const int32_t* snake_off, const int32_t* snake_nodes, const int32_t* snake_nstates,
                                       const char* snake_states, const char* seqs, const char* mfe_ss,
                                       const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
-                                      uint64_t* rng_state, char* out_seqs) {
+                                      uint32_t* rng_state, char* out_seqs) {
   if (R < 0 || L < 1 || L > 2048 || !target || !partner || !allowed_mask || n_snakes < 0 ||
       (n_snakes > 0 && (!snake_of || !snake_off || !snake_nodes || !snake_nstates || !snake_states)) ||
       (R > 0 && (!seqs || !mfe_ss || !shelf_index || !rng_state || !out_seqs)))
@@ -1017,13 +1035,13 @@ extern "C" int drna_propose_batch_alt(int R, int L, const char* target, const in
 }
 
 extern "C" int drna_metropolis_batch(int R, const double* score_o, const double* score_m, const double* temps, double Lconst,
-                                     uint64_t* rng_state, unsigned char* accept, unsigned char* better) {
+                                     uint32_t* rng_state, unsigned char* accept, unsigned char* better) {
   if (R < 0 || (R > 0 && (!score_o || !score_m || !temps || !rng_state || !accept || !better))) return DRNA_ERR_ARG;
   for (int r = 0; r < R; r++) {
     if (score_m[r] <= score_o[r]) { accept[r] = 1; better[r] = 1; continue; }
     better[r] = 0;
     const double p = std::exp((-Lconst / temps[r]) * (score_m[r] - score_o[r]));
-    accept[r] = p > drna_host::rnd01(rng_state[r]) ? 1 : 0;      // one draw, only when the mutant is worse
+    accept[r] = p > drna_host::rnd01(drna_host::Mt{rng_state + (size_t)r * drna_host::RNG_WORDS}) ? 1 : 0;   // one draw, only when the mutant is worse
   }
   return DRNA_OK;
 }
@@ -1035,7 +1053,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
                            const int32_t* snake_nodes, const int32_t* snake_nstates, const char* snake_states,
                            const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
                            const double* temps, double Lconst, int n_terms, const int32_t* term_id, const double* term_w,
-                           uint32_t flags, uint64_t* rng_state, char* seqs, char* mfe_ss, double* score, double* mcc1,
+                           uint32_t flags, uint32_t* rng_state, char* seqs, char* mfe_ss, double* score, double* mcc1,
                            double* Epf, double* Ed, int64_t* counters, char* best_seq, char* best_ss, double* best) {
   using namespace drna_host;
   if (!e) return DRNA_ERR_ARG;

@@ -9,9 +9,13 @@
 // positives of the current MFE structure widened by +-3 (position 0 never enters),
 // chosen with the per-shelf probability, else a uniform mutable position; unpaired positions change to a
 // different allowed letter, paired positions change together to a compatible (WC or GU) pair.  The random
-// stream is one splitmix64 state per replica (the reference uses one Python Mersenne stream per replica,
-// re-seeded every exchange step); draws are not bit-compatible with CPython's, which the reference's own
-// set-ordering dependence makes moot (see desirna_amd/design.py).
+// stream is the reference's: one MT19937 state per replica with CPython's seeding (random.seed(int) = init_by_array of
+// the integer's 32-bit digits) and CPython's draw mapping -- random() = (a >> 5, b >> 6) 53-bit, choice() =
+// _randbelow_with_getrandbits (rejection on getrandbits(bit_length(n))), choices([a, b], weights) = one random()
+// bisected on the cumulative weights -- so that a replica re-seeded with its index every exchange step
+// (utils/replica_exchange_monte_carlo.py:227-228,250) draws the same positions and letters as the reference's worker
+// does (tests/test_host_golden.py: the 900 recorded proposals; the reference's own dependence on str-set iteration
+// order for the second letter of a pair move and the snake state order is the only exemption).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -22,14 +26,84 @@
 
 namespace drna_host {
 
-static inline uint64_t splitmix64(uint64_t& s) {
-  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// ---- MT19937 with CPython's interface (Lib/random.py, Modules/_randommodule.c; the public Mersenne Twister algorithm)
+constexpr int MT_N = 624, MT_M = 397;
+constexpr int RNG_WORDS = MT_N + 1;           // state words per replica in the C ABI: mt[624] + index
+
+struct Mt {
+  uint32_t* mt;                               // 624 state words followed by the index
+  uint32_t& idx() { return mt[MT_N]; }
+};
+
+static inline void mt_init_genrand(Mt g, uint32_t s) {
+  g.mt[0] = s;
+  for (int i = 1; i < MT_N; i++) g.mt[i] = 1812433253u * (g.mt[i - 1] ^ (g.mt[i - 1] >> 30)) + (uint32_t)i;
+  g.idx() = MT_N;
 }
-static inline double rnd01(uint64_t& s) { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); }
-static inline int rnd_below(uint64_t& s, int n) { return (int)(rnd01(s) * n) % (n > 0 ? n : 1); }
+static inline void mt_init_by_array(Mt g, const uint32_t* key, int len) {
+  mt_init_genrand(g, 19650218u);
+  int i = 1, j = 0;
+  for (int k = MT_N > len ? MT_N : len; k; k--) {
+    g.mt[i] = (g.mt[i] ^ ((g.mt[i - 1] ^ (g.mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    i++; j++;
+    if (i >= MT_N) { g.mt[0] = g.mt[MT_N - 1]; i = 1; }
+    if (j >= len) j = 0;
+  }
+  for (int k = MT_N - 1; k; k--) {
+    g.mt[i] = (g.mt[i] ^ ((g.mt[i - 1] ^ (g.mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    i++;
+    if (i >= MT_N) { g.mt[0] = g.mt[MT_N - 1]; i = 1; }
+  }
+  g.mt[0] = 0x80000000u;
+}
+// random.seed(a) for a non-negative integer a < 2^64: the key is a's 32-bit digits, least significant first (one digit for 0)
+static inline void mt_seed_int(Mt g, uint64_t a) {
+  uint32_t key[2] = {(uint32_t)(a & 0xffffffffull), (uint32_t)(a >> 32)};
+  mt_init_by_array(g, key, key[1] ? 2 : 1);
+}
+static inline uint32_t mt_genrand(Mt g) {
+  static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+  if (g.idx() >= (uint32_t)MT_N) {
+    int kk;
+    uint32_t y;
+    for (kk = 0; kk < MT_N - MT_M; kk++) {
+      y = (g.mt[kk] & 0x80000000u) | (g.mt[kk + 1] & 0x7fffffffu);
+      g.mt[kk] = g.mt[kk + MT_M] ^ (y >> 1) ^ mag01[y & 1u];
+    }
+    for (; kk < MT_N - 1; kk++) {
+      y = (g.mt[kk] & 0x80000000u) | (g.mt[kk + 1] & 0x7fffffffu);
+      g.mt[kk] = g.mt[kk + (MT_M - MT_N)] ^ (y >> 1) ^ mag01[y & 1u];
+    }
+    y = (g.mt[MT_N - 1] & 0x80000000u) | (g.mt[0] & 0x7fffffffu);
+    g.mt[MT_N - 1] = g.mt[MT_M - 1] ^ (y >> 1) ^ mag01[y & 1u];
+    g.idx() = 0;
+  }
+  uint32_t y = g.mt[g.idx()++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+// random.random()
+static inline double rnd01(Mt g) {
+  const uint32_t a = mt_genrand(g) >> 5, b = mt_genrand(g) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+// random.choice(seq) index = Random._randbelow_with_getrandbits(n), 0 < n < 2^32
+static inline int rnd_below(Mt g, int n) {
+  if (n <= 0) return 0;
+  const int k = 32 - __builtin_clz((unsigned)n);          // n.bit_length()
+  uint32_t r = mt_genrand(g) >> (32 - k);
+  while (r >= (uint32_t)n) r = mt_genrand(g) >> (32 - k);
+  return (int)r;
+}
+// random.choices([first, second], weights=[w, 1 - w])[0]: 0 = first
+static inline int rnd_choices2(Mt g, double w) {
+  const double c0 = w, c1 = w + (1.0 - w);                // itertools.accumulate
+  const double x = rnd01(g) * (c1 + 0.0);
+  return x < c0 ? 0 : 1;                                  // bisect_right(cum_weights, x, 0, 1)
+}
 
 static inline int bracket_family(char ch, bool& open) {
   static const char OP[] = "([<{ABCDE", CL[] = ")]>}abcde";

@@ -276,13 +276,29 @@ class DesignProblem:
         return "".join(s)
 
 
+def _sws_reached(simulation_data, num_results, oligo_state):
+    """The reference's -sws test (utils/stats_inputs_outputs.py:240-264, run every 10th exchange step): records
+    de-duplicated by sequence, sorted like the result file, cut to num_results -- stop when all of them are solved."""
+    from . import outputs
+    top = outputs.sort_and_filter(simulation_data, num_results, oligo_state=oligo_state)
+    return len(top) == num_results and all(r["mcc"] == 0.0 for r in top)
+
+
 def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off", acgu=None, subopt="off"):
+               device=0, shards=None, scorer=None, progress=None, dimer="off", oligo="off", acgu=None, subopt="off",
+               num_results=None):
     """Replica-exchange Monte-Carlo design of one target.  Returns dict(best=ScoreSeq, solved=bool, history=..., stats=...).
 
     ``shards`` (a ``replica_exchange.ReplicaShards``) splits the replicas over ranks; every rank proposes and scores its
-    own replicas and all-gathers the scores before each exchange attempt."""
+    own replicas; ONE all-gather per exchange step carries the scores (and the ranks' solved / time-is-up flags), then every
+    rank replays the same swaps on the whole temperature ladder, which it tracks itself.  Stop decisions are collective:
+    they are taken from the gathered flags (rank 0's clock decides the time limit), so no rank leaves the loop alone.
+
+    Loop semantics of the reference (``DesiRNA.py:361-383``): the time limit holds also when ``steps`` is given; records
+    carry ``sim_step = global_step * exchange``; ``stop_when_solved`` with ``num_results`` is the reference's ``-sws on``
+    (every 10th step: stop when the best ``num_results`` distinct sequences are all solved), without it the run stops at the
+    first solved replica (an extension used by the tests and by the puzzle-set driver)."""
     prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs, acgu=acgu)
     pks = "on" if set(input_file.sec_struct) - set(".()&") else "off"
     if prob.two_strands:
@@ -294,9 +310,10 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
     shards = shards or rx.ReplicaShards(replicas, 0, 1)
     local = shards.local
     scorer = scorer or es.ReplicaScorer(input_file, opts, max_replicas=max(1, len(local)), device=device)
-    temps = rx.get_rep_temps(replicas, t_min, t_max)
+    temps = rx.get_rep_temps(replicas, t_min, t_max)           # temperature shelf of EVERY replica, replayed on every rank
     shelves = list(temps)
-    main_rng = random.Random(2137 + seed) if seed else random.Random()
+    # main stream (initial sequence, swap acceptance; DesiRNA.py:659-664): the same on every rank
+    main_rng = random.Random(shards.broadcast_seed(2137 + seed if seed else random.random()))
     init = prob.initial_sequence(main_rng)
     # input_file.seed_seq is read but ignored, as in the reference
     cur = scorer.score([init] * len(local)) if local else []
@@ -309,12 +326,12 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
     t_start = time.time()
     global_step = 0
     solved = best is not None and best.mcc == 0.0
-    while True:
+    if shards.world > 1:                                      # a solved start must be known to every rank before the loop
+        _, ex = shards.allgather_scores([s.scoring_function for s in cur], extras=[float(solved)])
+        solved = bool(ex[:, 0].any())
+    stop = stop_when_solved and solved and num_results is None
+    while not stop:
         if steps is not None and global_step >= steps:
-            break
-        if steps is None and time.time() - t_start >= timelimit:
-            break
-        if stop_when_solved and solved:
             break
         global_step += 1
         rngs = [random.Random(r) for r in local]              # re-seeded with the replica index every exchange step
@@ -331,7 +348,7 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
                 if acc:
                     cand[k].get_replica_num(cur[k].replica_num)
                     cand[k].get_temp_shelf(cur[k].temp_shelf)
-                    cand[k].get_sim_step(global_step)
+                    cand[k].get_sim_step(global_step * exchange)
                     cur[k] = cand[k]
                     stats["acc_mc"] += 1
                     stats["acc_mc_better"] += int(better)
@@ -339,30 +356,43 @@ def run_design(input_file, replicas=10, exchange=100, steps=None, timelimit=60, 
                         best = cur[k]
                 else:
                     stats["rej_mc"] += 1
-        solved = solved or any(s.mcc == 0.0 for s in cur)
-        # replica exchange: all ranks see all scores and replay the same swaps on the temperature labels
-        all_scores = shards.allgather_scores([s.scoring_function for s in cur])
-        all_temps = shards.allgather_scores([s.temp_shelf for s in cur])
-        new_temps, acc, _, rej = rx.replica_exchange(list(all_temps), list(all_scores), global_step, main_rng)
+        # replica exchange: ONE all-gather (scores + control flags); all ranks replay the same swaps on the whole ladder
+        flags = [float(any(s.mcc == 0.0 for s in cur)), float(time.time() - t_start >= timelimit), 0.0]
+        for k, r in enumerate(local):
+            cur[k].get_sim_step(global_step * exchange)       # reference DesiRNA.py:371-373: stats.step = global_step * RE_attempt
+        if stop_when_solved and num_results is not None and global_step % 10 == 0:
+            flags[2] = float(_sws_reached(simulation_data + [dict(vars(s)) for s in cur], num_results, oligo_state))
+        all_scores, ex = shards.allgather_scores([s.scoring_function for s in cur], extras=flags)
+        solved = solved or bool(ex[:, 0].any())
+        temps, acc, _, rej = rx.replica_exchange(list(temps), list(all_scores), global_step, main_rng)
         stats["acc_re"] += acc
         stats["rej_re"] += rej
         for k, r in enumerate(local):
-            cur[k].get_temp_shelf(new_temps[r])
-            cur[k].get_sim_step(global_step)
+            cur[k].get_temp_shelf(temps[r])
         simulation_data += [dict(vars(s)) for s in cur]       # reference DesiRNA.py:375
         if progress:
             progress(global_step, best, stats)
+        stop = bool(ex[0, 1]) or (stop_when_solved and (solved if num_results is None else bool(ex[:, 2].all())))
+    if shards.world > 1:                                      # the best replica of the whole job, on every rank
+        cands = rx.gather_results({shards.rank: best}, shards.world)
+        best = min((b for b in cands.values() if b is not None), key=lambda s: (s.mcc, s.scoring_function))
     stats["elapsed_s"] = time.time() - t_start
-    return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step,
+    return {"best": best, "solved": solved, "replicas": cur, "stats": stats, "steps": global_step, "temps": list(temps),
             "simulation_data": simulation_data, "engine": getattr(scorer, "engine", None)}
 
 
 def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit=60, t_min=10.0, t_max=150.0,
                     scoring_f="Ed-Epf:1.0", tm_max=0.7, tm_min=0.0, point_mutations="on", seed=0, stop_when_solved=False,
-                    device=0, engine=None, keep_records=True, native_loop=None):
+                    device=0, engine=None, keep_records=True, native_loop=None, shards=None, num_results=None):
     """Same loop as :func:`run_design` with the per-replica host work in native code and no per-step Python objects:
-    proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.
-    Per-replica random streams are splitmix64 states seeded with the replica index at every exchange step."""
+    proposals, SimScore and Metropolis run batched in the C library, the replica state lives in numpy arrays.  The
+    per-replica random streams are the reference's (MT19937 seeded with the replica index at every exchange step, CPython's
+    draw mapping: ``host_driver.hpp``), so for a fixed seed this driver and :func:`run_design` walk the same trajectory.
+
+    ``shards`` (``replica_exchange.ReplicaShards``): this rank holds replicas ``shards.local`` only (its engine needs
+    ``max_R >= len(shards.local)``); per exchange step ONE all-gather carries the scores and the stop flags, every rank
+    replays the swaps on the whole ladder.  Results do not depend on the sharding (streams are seeded by the GLOBAL
+    replica index and the kernels' results do not depend on the batch composition)."""
     from . import engine as _engine
     prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
     if prob.two_strands:
@@ -372,17 +402,19 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     for name, _ in sf:
         if name not in es.AVAILABLE_SCORING_FUNCTIONS:
             raise ValueError("%s is not an available option for scoring function. Check your command." % name)
-    R, L = replicas, prob.n
-    eng = engine or _engine.Engine(max_R=R, max_L=L, device=device)
+    shards = shards or rx.ReplicaShards(replicas, 0, 1)
+    local = np.array(shards.local, dtype=np.int64)
+    R, L, Rl = replicas, prob.n, len(shards.local)
+    eng = engine or _engine.Engine(max_R=max(1, Rl), max_L=L, device=device)
     hk = _engine.HostKernels()
     eng.set_targets([input_file.sec_struct] + list(input_file.alt_sec_structs or []))
     flags = _engine.NEED_PF | _engine.NEED_MFE | _engine.NEED_EVAL
     if set(input_file.sec_struct) - set(".()&"):
         flags |= _engine.NEED_PK
     amask = np.array([sum(1 << "ACGU".index(c) for c in a) for a in prob.allowed], dtype=np.uint8)
-    temps = np.array(rx.get_rep_temps(R, t_min, t_max), dtype=np.float64)
+    temps = np.array(rx.get_rep_temps(R, t_min, t_max), dtype=np.float64)      # the whole ladder, replayed on every rank
     shelves = temps.copy()
-    main_rng = random.Random(2137 + seed) if seed else random.Random()
+    main_rng = random.Random(shards.broadcast_seed(2137 + seed if seed else random.random()))
     ref_ss = input_file.sec_struct
 
     def score(seqs_u8):
@@ -410,26 +442,26 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         return total, 1 - mcc, ss, Epf, ed
 
     init = prob.initial_sequence(main_rng)
-    cur = np.tile(np.frombuffer(init.encode(), dtype=np.uint8), (R, 1)).copy()
+    cur = np.tile(np.frombuffer(init.encode(), dtype=np.uint8), (max(1, Rl), 1)).copy()
     cur_score, cur_mcc, cur_ss, cur_epf, cur_ed = score(cur)
     k0 = int(np.lexsort((cur_score, cur_mcc))[0])
     best = dict(sequence=cur[k0].tobytes().decode(), mfe_ss=cur_ss[k0].tobytes().decode(), mcc=float(cur_mcc[k0]),
                 scoring_function=float(cur_score[k0]), Epf=float(cur_epf[k0]), edesired=float(cur_ed[k0]))
-    stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=R)
+    stats = dict(acc_mc=0, acc_mc_better=0, rej_mc=0, acc_re=0, rej_re=0, scored=Rl)
 
     def records(step_no):
         out = []
-        for r in range(R):
-            sc = es.ScoreSeq(cur[r].tobytes().decode())
-            sc.scoring_function = float(cur_score[r])
-            sc.get_replica_num(r + 1)
-            sc.get_temp_shelf(float(temps[r]))
+        for k in range(Rl):
+            sc = es.ScoreSeq(cur[k].tobytes().decode())
+            sc.scoring_function = float(cur_score[k])
+            sc.get_replica_num(int(local[k]) + 1)
+            sc.get_temp_shelf(float(temps[local[k]]))
             sc.get_sim_step(step_no)
-            sc.get_Epf(float(cur_epf[r]))
-            sc.get_edesired(float(cur_ed[r]))
+            sc.get_Epf(float(cur_epf[k]))
+            sc.get_edesired(float(cur_ed[k]))
             sc.get_edesired_minus_Epf(sc.Epf, sc.edesired)
-            sc.mcc = float(cur_mcc[r])
-            sc.get_mfe_ss(cur_ss[r].tobytes().decode())
+            sc.mcc = float(cur_mcc[k])
+            sc.get_mfe_ss(cur_ss[k].tobytes().decode())
             out.append(dict(vars(sc)))
         return out
 
@@ -440,60 +472,70 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     cur = np.ascontiguousarray(cur); cur_ss = np.ascontiguousarray(cur_ss)
     cur_score = np.ascontiguousarray(cur_score, dtype=np.float64); cur_mcc = np.ascontiguousarray(cur_mcc, dtype=np.float64)
     cur_epf = np.ascontiguousarray(cur_epf, dtype=np.float64); cur_ed = np.ascontiguousarray(cur_ed, dtype=np.float64)
+    rng_state = np.empty((max(1, Rl), _engine.RNG_WORDS), dtype=np.uint32)
     t_start = time.time()
     step = 0
     solved = best["mcc"] == 0.0
+    if shards.world > 1:
+        _, ex = shards.allgather_scores(cur_score[:Rl], extras=[float(solved)])
+        solved = bool(ex[:, 0].any())
     targeted = point_mutations == "on"
-    while True:
+    stop = stop_when_solved and solved and num_results is None
+    while not stop:
         if steps is not None and step >= steps:
             break
-        if steps is None and time.time() - t_start >= timelimit:
-            break
-        if stop_when_solved and solved:
-            break
         step += 1
-        rng_state = np.arange(R, dtype=np.uint64)                # re-seeded with the replica index every exchange step
-        shelf_idx = np.searchsorted(shelves, temps).astype(np.int32)
-        if native_loop:
+        hk.rng_seed(local if Rl else [0], out=rng_state)        # random.seed(replica index) at every exchange step (App. C2)
+        tl = temps[local] if Rl else temps[:1]
+        shelf_idx = np.searchsorted(shelves, tl).astype(np.int32)
+        if native_loop and Rl:
             # the whole inner loop of the exchange step in native code (drna_mc_run): one call, no per-iteration Python
             state = dict(seqs=cur, mfe_ss=cur_ss, score=cur_score, mcc1=cur_mcc, Epf=cur_epf, Ed=cur_ed)
             counters = np.zeros(3, dtype=np.int64)
             bst = dict(seq=np.frombuffer(best["sequence"].encode(), dtype=np.uint8).copy(),
                        ss=np.frombuffer(best["mfe_ss"].encode(), dtype=np.uint8).copy(),
                        vals=np.array([best["mcc"], best["scoring_function"], best["Epf"], best["edesired"]], dtype=np.float64))
-            eng.mc_run(prob, exchange, shelf_idx, R, tm_max, tm_min, targeted, temps, sf, flags, rng_state, state, counters, bst)
+            eng.mc_run(prob, exchange, shelf_idx, R, tm_max, tm_min, targeted, np.ascontiguousarray(tl), sf, flags, rng_state, state,
+                       counters, bst)
             best = dict(sequence=bst["seq"].tobytes().decode(), mfe_ss=bst["ss"].tobytes().decode(), mcc=float(bst["vals"][0]),
                         scoring_function=float(bst["vals"][1]), Epf=float(bst["vals"][2]), edesired=float(bst["vals"][3]))
             stats["acc_mc"] += int(counters[0]); stats["acc_mc_better"] += int(counters[1]); stats["rej_mc"] += int(counters[2])
-            stats["scored"] += R * exchange
-        for _ in range(0 if native_loop else exchange):
-            if prob.snakes or n_alt:
-                prop = hk.propose_alt(prob, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
-            else:
-                prop = hk.propose(ref_ss, amask, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
+            stats["scored"] += Rl * exchange
+        for _ in range(0 if (native_loop or not Rl) else exchange):
+            prop = hk.propose_alt(prob, cur, cur_ss, shelf_idx, R, tm_max, tm_min, targeted, rng_state)
             p_score, p_mcc, p_ss, p_epf, p_ed = score(prop)
-            acc, better = hk.metropolis(cur_score, p_score, temps, rng_state)
+            acc, better = hk.metropolis(cur_score, p_score, tl, rng_state)
             cur[acc] = prop[acc]; cur_ss[acc] = p_ss[acc]
             cur_score[acc] = p_score[acc]; cur_mcc[acc] = p_mcc[acc]; cur_epf[acc] = p_epf[acc]; cur_ed[acc] = p_ed[acc]
             na = int(acc.sum())
             stats["acc_mc"] += na
             stats["acc_mc_better"] += int((acc & better).sum())
-            stats["rej_mc"] += R - na
-            stats["scored"] += R
-            kb = int(np.lexsort((cur_score, cur_mcc))[0])
-            if (cur_mcc[kb], cur_score[kb]) < (best["mcc"], best["scoring_function"]):
-                best = dict(sequence=cur[kb].tobytes().decode(), mfe_ss=cur_ss[kb].tobytes().decode(), mcc=float(cur_mcc[kb]),
-                            scoring_function=float(cur_score[kb]), Epf=float(cur_epf[kb]), edesired=float(cur_ed[kb]))
-        solved = solved or bool((cur_mcc == 0.0).any())
-        new_temps, a, _, rj = rx.replica_exchange(list(temps), list(cur_score), step, main_rng)
+            stats["rej_mc"] += Rl - na
+            stats["scored"] += Rl
+            # the best state is tracked replica by replica in replica order, like the native loop (first strictly better wins)
+            for kb in np.nonzero(acc)[0]:
+                if (cur_mcc[kb], cur_score[kb]) < (best["mcc"], best["scoring_function"]):
+                    best = dict(sequence=cur[kb].tobytes().decode(), mfe_ss=cur_ss[kb].tobytes().decode(), mcc=float(cur_mcc[kb]),
+                                scoring_function=float(cur_score[kb]), Epf=float(cur_epf[kb]), edesired=float(cur_ed[kb]))
+        # ONE collective per exchange step: scores + (solved, time is up); rank 0's clock decides the time limit
+        ctl = [float(bool(Rl) and bool((cur_mcc[:Rl] == 0.0).any())), float(time.time() - t_start >= timelimit), 0.0]
+        if stop_when_solved and num_results is not None and keep_records and step % 10 == 0:      # the reference's -sws rule
+            ctl[2] = float(_sws_reached(simulation_data + records(step * exchange), num_results, "none"))
+        all_scores, ex = shards.allgather_scores(cur_score[:Rl], extras=ctl)
+        solved = solved or bool(ex[:, 0].any())
+        new_temps, a, _, rj = rx.replica_exchange(list(temps), list(all_scores), step, main_rng)
         temps = np.array(new_temps, dtype=np.float64)
         stats["acc_re"] += a
         stats["rej_re"] += rj
         if keep_records:
-            simulation_data += records(step)
+            simulation_data += records(step * exchange)          # reference: stats.step = global_step * RE_attempt
+        stop = bool(ex[0, 1]) or (stop_when_solved and (solved if num_results is None else bool(ex[:, 2].all())))
+    if shards.world > 1:
+        cands = rx.gather_results({shards.rank: best if Rl else None}, shards.world)
+        best = min((b for b in cands.values() if b is not None), key=lambda b: (b["mcc"], b["scoring_function"]))
     stats["elapsed_s"] = time.time() - t_start
     return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data,
-            "engine": eng}
+            "engine": eng, "temps": [float(t) for t in temps], "local": [int(r) for r in local]}
 
 
 def run_puzzle_set(inputs, rank=0, world=1, driver=None, **kw):
@@ -528,6 +570,7 @@ def main(argv=None):
     ap.add_argument("-tm_perc_min", type=float, default=0.0, dest="tm_min")
     ap.add_argument("-seed", "--seed_number", type=int, default=0, dest="in_seed")
     ap.add_argument("-sws", "--stop_when_solved", default="off", choices=["off", "on"], dest="sws")
+    ap.add_argument("-r", "--results_number", type=int, default=10, dest="num_results")
     ap.add_argument("-d", "--dimer", default="off", choices=["off", "on"], dest="dimer", help="homodimer design (two-strand input)")
     ap.add_argument("-oa", "--avoid_oligomerization", default="off", choices=["off", "on"], dest="oligo")
     ap.add_argument("-nd", "--negative_design", default="off", choices=["off", "on"], dest="subopt")
@@ -547,7 +590,7 @@ def main(argv=None):
         extra["acgu"] = dict(zip("ACGU", vals))
     res = (run_design if (a.python_host or two) else run_design_fast)(inp, **extra, replicas=a.replicas, exchange=a.exchange, steps=a.steps, timelimit=a.timlim, t_min=a.t_min,
                      t_max=a.t_max, scoring_f=a.scoring_f, tm_max=a.tm_max, tm_min=a.tm_min, point_mutations=a.pm,
-                     seed=a.in_seed, stop_when_solved=a.sws == "on")
+                     seed=a.in_seed, stop_when_solved=a.sws == "on", num_results=a.num_results if a.sws == "on" else None)
     if a.outdir:
         import os
         from . import outputs
@@ -560,9 +603,11 @@ def main(argv=None):
         stats = SimpleNamespace(step=st["acc_mc"] + st["rej_mc"], global_step=res["steps"], acc_mc_step=st["acc_mc"],
                                 acc_mc_better_e=st["acc_mc_better"], rej_mc_step=st["rej_mc"], acc_re_step=st["acc_re"],
                                 rej_re_step=st["rej_re"])
+        oligo_state = ("homodimer" if a.dimer == "on" else "heterodimer") if "&" in inp.sec_struct else ("avoid" if a.oligo == "on" else "none")
         outputs.write_all(res["simulation_data"], inp.name, os.path.basename(a.name), outname, stats, st["elapsed_s"], a.timlim,
-                          time.strftime("%Y%m%d.%H%M%S"), directory=a.outdir,
-                          alt_sec_structs=list(inp.alt_sec_structs or []) or None, engine=res.get("engine"))
+                          time.strftime("%Y%m%d.%H%M%S"), num_results=a.num_results, directory=a.outdir,
+                          alt_sec_structs=list(inp.alt_sec_structs or []) or None, engine=res.get("engine"),
+                          oligo_state=oligo_state, subopt=a.subopt, sec_struct=inp.sec_struct)
     b = res["best"]
     print("Design solved succesfully!" if res["solved"] else "Design not solved.")
     print(b.sequence)

@@ -203,6 +203,12 @@ class ReplicaScorer:
         L = len(self.target)
         self.engine = engine or _engine.Engine(max_R=max_replicas, max_L=L, device=device,
                                                params=str(getattr(sim_options, "param", "1999")))
+        # -oa on folds every candidate against itself (s & s: 2 L nucleotides, reference :411-418): that needs an engine
+        # sized for 2 L; the scoring engine stays sized for L (its workspace pitch follows max_L)
+        self.dimer_engine = self.engine
+        if self.oligo_state == "avoid" and self.engine.max_L < 2 * L:
+            self.dimer_engine = _engine.Engine(max_R=max(max_replicas, 1), max_L=2 * L, device=device,
+                                               params=str(getattr(sim_options, "param", "1999")))
         targets = [self.target]
         if getattr(input_file, "alt_sec_struct", None) is not None:
             targets += [a.replace("&", "") for a in input_file.alt_sec_structs]
@@ -262,7 +268,7 @@ class ReplicaScorer:
         if self.oligo_state == "avoid":
             # reference get_scoring_function_monomer (:411-418): homodimer of the sequence with itself, monomer fraction bonus
             # (applied before the motif bonus in the reference; both are additive)
-            co = self.engine.cofold_batch([s + "&" + s for s in seqs], _engine.NEED_PF)
+            co = self.dimer_engine.cofold_batch([s + "&" + s for s in seqs], _engine.NEED_PF)
             for k, sc in enumerate(res):
                 sc.oligo_fraction = float(oligo_fraction(co["FA"][k], co["FB"][k], co["FcAB"][k]))
                 sc.monomer_bonus = float(kTlog_monomer_fraction(sc.oligo_fraction))

@@ -25,7 +25,9 @@ EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
            "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
-           "drna_subopt_structs_batch")
+           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random")
+
+RNG_WORDS = 625        # DRNA_RNG_WORDS: uint32 words of one replica's MT19937 stream
 
 
 class EngineError(RuntimeError):
@@ -87,6 +89,10 @@ def load_library(path=None):
                                          C.c_double, ci, vp, vp]
     L.drna_metropolis_batch.restype = ci
     L.drna_metropolis_batch.argtypes = [ci, vp, vp, vp, C.c_double, vp, vp, vp]
+    L.drna_rng_seed.restype = ci
+    L.drna_rng_seed.argtypes = [ci, vp, vp]
+    L.drna_rng_random.restype = ci
+    L.drna_rng_random.argtypes = [ci, vp, vp]
     return L
 
 
@@ -335,6 +341,25 @@ class HostKernels:
         prob._native_pack = (am, partner, snake_of, np.array(off, dtype=np.int32), np.array(nodes or [0], dtype=np.int32),
                              np.array(nst or [0], dtype=np.int32), np.frombuffer(chars or b".", dtype=np.uint8).copy())
 
+    def rng_seed(self, seeds, out=None):
+        """One MT19937 stream per entry of `seeds`, seeded like ``random.seed(int)`` (the reference re-seeds every worker
+        with its replica index at each exchange step, utils/replica_exchange_monte_carlo.py:227-228,250)."""
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        st = out if out is not None else np.empty((sd.shape[0], RNG_WORDS), dtype=np.uint32)
+        assert st.dtype == np.uint32 and st.shape == (sd.shape[0], RNG_WORDS) and st.flags.c_contiguous
+        rc = self._L.drna_rng_seed(sd.shape[0], sd.ctypes.data, st.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_rng_seed")
+        return st
+
+    def rng_random(self, rng_state):
+        """one ``random.random()`` from every stream"""
+        out = np.empty(rng_state.shape[0])
+        rc = self._L.drna_rng_random(rng_state.shape[0], rng_state.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, "drna_rng_random")
+        return out
+
     def simscore(self, ref, queries_u8):
         """ref: reference structure string ('&' -> 'Ee' already applied); queries_u8: (R, L) uint8.
         Returns rounded (mcc, recall, precision) arrays exactly as the reference's SimScore computes them."""
@@ -354,7 +379,7 @@ class HostKernels:
         ss = np.ascontiguousarray(ss_u8, dtype=np.uint8)
         am = np.ascontiguousarray(allowed_mask, dtype=np.uint8)
         sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
-        assert rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+        assert rng_state.dtype == np.uint32 and rng_state.shape == (R, RNG_WORDS) and rng_state.flags.c_contiguous
         rc = self._L.drna_propose_batch(R, L, target.encode("ascii"), am.ctypes.data, s.ctypes.data, ss.ctypes.data,
                                         sh.ctypes.data, int(n_shelves), float(tm_max), float(tm_min), int(bool(targeted)),
                                         rng_state.ctypes.data, out.ctypes.data)
@@ -374,7 +399,7 @@ class HostKernels:
             pk = prob._native_pack
         am, partner, snake_of, off, nodes, nst, chars = pk
         sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
-        assert rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+        assert rng_state.dtype == np.uint32 and rng_state.shape == (R, RNG_WORDS) and rng_state.flags.c_contiguous
         rc = self._L.drna_propose_batch_alt(R, L, prob.sec_struct.encode("ascii"), partner.ctypes.data, am.ctypes.data,
                                             snake_of.ctypes.data, len(prob.snakes), off.ctypes.data, nodes.ctypes.data,
                                             nst.ctypes.data, chars.ctypes.data, s.ctypes.data, ss.ctypes.data, sh.ctypes.data,

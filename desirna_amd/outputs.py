@@ -56,12 +56,23 @@ def best_fasta_text(simulation_data, infile, now, num_results=10):
     return "".join(f">{infile}|{now}|{s['replica_num']}|{s['sim_step']}|{s['scoring_function']}\n{s['sequence']}\n" for s in top)
 
 
-def sort_and_filter(simulation_data, num_results=10):
-    """Unique sequences (last occurrence wins), best first: lowest 1-MCC, then Ed-Epf, Epf, scoring function."""
+def sort_and_filter(simulation_data, num_results=10, oligo_state="none", subopt="off", sec_struct=None):
+    """Unique sequences (last occurrence wins), best first (reference ``sort_and_filter_simulation_data``,
+    ``utils/stats_inputs_outputs.py:384-419``): lowest 1-MCC, then by branch -- ``-oa on``: scoring function, Ed-Epf, Epf;
+    ``-d on``: oligomer fraction (ascending for two different strands, descending for two equal ones), Ed-Epf, Epf;
+    ``-nd on``: Ed-Epf, then the LARGEST Esubopt-Epf; plain: Ed-Epf, Epf, scoring function."""
     uniq = list({item['sequence']: item for item in simulation_data}.values())
-    res = sorted(_round_records(uniq), key=lambda d: (-d['mcc'], -d['edesired_minus_Epf'], -d['Epf'], -d['scoring_function']),
-                 reverse=True)
-    return res[:num_results]
+    if oligo_state == "avoid":
+        key = lambda d: (-d['mcc'], -d['scoring_function'], -d['edesired_minus_Epf'], -d['Epf'])
+    elif oligo_state == "homodimer":
+        a, b = (sec_struct or "&").split("&")[:2]
+        sign = 1.0 if a != b else -1.0
+        key = lambda d: (-d['mcc'], sign * d['oligo_fraction'], -d['edesired_minus_Epf'], -d['Epf'])
+    elif subopt != "off":
+        key = lambda d: (-d['mcc'], -d['edesired_minus_Epf'], d['esubopt_minus_Epf'])
+    else:
+        key = lambda d: (-d['mcc'], -d['edesired_minus_Epf'], -d['Epf'], -d['scoring_function'])
+    return sorted(_round_records(uniq), key=key, reverse=True)[:num_results]
 
 
 def get_alt_mcc(simulation_data, alt_sec_structs, engine):
@@ -147,7 +158,7 @@ def get_outname(infile, replicas, RE_attempt, timlim, pks, acgu_percentages, T_m
 
 
 def write_all(simulation_data, input_name, infile, outname, stats, finish_time, timlim, now, num_results=10, directory=".",
-              alt_sec_structs=None, engine=None):
+              alt_sec_structs=None, engine=None, oligo_state="none", subopt="off", sec_struct=None):
     """Write _traj.csv, _multifasta.fas, _best_fasta.fas, _results.csv, _best_str and _stats (reference
     parse_and_output_results, :593-633).  With alternative structures the ranking is sort_and_filter_alternative and
     _traj.csv is rewritten from its augmented records, as the reference does.  Returns (sorted_results, solved)."""
@@ -165,7 +176,7 @@ def write_all(simulation_data, input_name, infile, outname, stats, finish_time, 
         with open(base + '_traj.csv', 'w', newline='', encoding='utf-8') as fh:
             fh.write(trajectory_csv_text(aug))
     else:
-        res = sort_and_filter(simulation_data, num_results)
+        res = sort_and_filter(simulation_data, num_results, oligo_state=oligo_state, subopt=subopt, sec_struct=sec_struct)
     with open(base + '_results.csv', 'w', newline='', encoding='utf-8') as fh:
         fh.write(results_csv_text(res))
     txt, ok = check_if_design_solved(res[:10], input_name)

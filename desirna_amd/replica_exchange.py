@@ -91,24 +91,46 @@ class ReplicaShards:
     def owner(self, r):
         return r % self.world
 
-    def allgather_scores(self, local_scores, device=None):
+    def allgather_scores(self, local_scores, device=None, extras=None):
         """local_scores: this rank's scores in self.local order -> all R scores in replica order.
 
-        One all-gather of ceil(R/world) fp64 per rank (RCCL over xGMI with backend 'nccl', gloo on CPU)."""
+        THE collective of an exchange step: one all-gather of ceil(R/world) (+ len(extras)) fp64 per rank (RCCL over xGMI
+        with backend 'nccl' -- the tensors then live on this rank's GPU --, gloo on CPU).  `extras` are a few per-rank
+        control values that ride in the same buffer (solved / time-is-up flags of the design loop); with extras the
+        return value is (scores, extras_of_every_rank[world, len(extras)])."""
+        ne = 0 if extras is None else len(extras)
         if self.world == 1:
-            return np.asarray(local_scores, dtype=np.float64).copy()
+            full = np.asarray(local_scores, dtype=np.float64).copy()
+            return full if extras is None else (full, np.asarray(extras, dtype=np.float64).reshape(1, ne))
         import torch
         import torch.distributed as dist
-        buf = torch.full((self.max_local,), float("nan"), dtype=torch.float64, device=device)
-        buf[:len(self.local)] = torch.as_tensor(np.asarray(local_scores, dtype=np.float64), device=device)
-        out = torch.empty(self.world * self.max_local, dtype=torch.float64, device=device)
+        if device is None and dist.get_backend() == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        width = self.max_local + ne
+        host = np.full(width, np.nan, dtype=np.float64)
+        host[:len(self.local)] = np.asarray(local_scores, dtype=np.float64)
+        if ne:
+            host[self.max_local:] = np.asarray(extras, dtype=np.float64)
+        buf = torch.as_tensor(host, device=device)
+        out = torch.empty(self.world * width, dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(out, buf)
-        out = out.cpu().numpy().reshape(self.world, self.max_local)
+        out = out.cpu().numpy().reshape(self.world, width)
         full = np.empty(self.R, dtype=np.float64)
         for rk in range(self.world):
             idx = list(range(rk, self.R, self.world))
             full[idx] = out[rk, :len(idx)]
-        return full
+        return full if extras is None else (full, out[:, self.max_local:].copy())
+
+    def broadcast_seed(self, seed):
+        """Every rank must replay the same swap decisions and start from the same sequence, so the main stream's seed
+        is rank 0's: an unseeded run (seed 0 = random.seed(random.random()) in the reference, DesiRNA.py:659-664) draws
+        it on rank 0 and sends it to the others."""
+        if self.world == 1:
+            return seed
+        import torch.distributed as dist
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
 
 def shard_puzzles(lengths, world):

@@ -177,6 +177,17 @@ int drna_simscore_batch(int R, int L, const char *ref, const char *queries, doub
                         double *precision);
 
 /*
+ * Per-replica random streams of the host helpers: the reference's worker calls random.seed(replica_index) at the start of
+ * every exchange step (utils/replica_exchange_monte_carlo.py:227-228 with seeds = [0 .. R-1], :250) and then draws from
+ * Python's global Mersenne Twister.  drna_rng_seed(seeds) = random.seed(int) for each of R streams (MT19937 init_by_array
+ * on the integer's 32-bit digits); drna_rng_random = one random.random() per stream (53-bit, two outputs).
+ *   rng_state   R * DRNA_RNG_WORDS uint32 (624 state words + position), owned by the caller
+ */
+#define DRNA_RNG_WORDS 625
+int drna_rng_seed(int R, const uint64_t *seeds, uint32_t *rng_state);
+int drna_rng_random(int R, uint32_t *rng_state, double *out);
+
+/*
  * drna_propose_batch: one proposal per replica, the move set of mutate_sequence / get_mutation_position /
  * expand_cases (utils/sequence_utils.py:926-1136) for single-chain targets without alternative structures.
  *   target        L chars, every bracket family is a design pair
@@ -184,12 +195,13 @@ int drna_simscore_batch(int R, int L, const char *ref, const char *queries, doub
  *   seqs, mfe_ss  R*L chars: current sequence and current MFE structure of each replica
  *   shelf_index   R ints: index of the replica's temperature shelf; the targeted-mutation probability is
  *                 round(linspace(tm_max, tm_min, n_shelves)[index], 2) (:963-967)
- *   rng_state     R uint64, one stream per replica, advanced in place
+ *   rng_state     R * DRNA_RNG_WORDS uint32: one MT19937 stream per replica (drna_rng_seed), advanced in place; the
+ *                 draws are CPython's (random(), choice(), choices()), in the order of the reference's code
  *   out_seqs      R*L chars
  */
 int drna_propose_batch(int R, int L, const char *target, const unsigned char *allowed_mask, const char *seqs,
                        const char *mfe_ss, const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min,
-                       int targeted, uint64_t *rng_state, char *out_seqs);
+                       int targeted, uint32_t *rng_state, char *out_seqs);
 
 /*
  * drna_propose_batch_alt: the same move set for targets WITH alternative structures (>alt_sec_struct): positions that sit
@@ -206,14 +218,14 @@ int drna_propose_batch_alt(int R, int L, const char *target, const int32_t *part
                            const int32_t *snake_of, int n_snakes, const int32_t *snake_off, const int32_t *snake_nodes,
                            const int32_t *snake_nstates, const char *snake_states, const char *seqs, const char *mfe_ss,
                            const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
-                           uint64_t *rng_state, char *out_seqs);
+                           uint32_t *rng_state, char *out_seqs);
 
 /*
  * drna_metropolis_batch: mc_delta of utils/replica_exchange_monte_carlo.py:26-57 for R replicas: accept iff
  * score_m <= score_o, else with probability exp(-Lconst / T * (score_m - score_o)) (one draw, only then).
  */
 int drna_metropolis_batch(int R, const double *score_o, const double *score_m, const double *temps, double Lconst,
-                          uint64_t *rng_state, unsigned char *accept, unsigned char *better);
+                          uint32_t *rng_state, unsigned char *accept, unsigned char *better);
 
 /*
  * drna_mc_run: n_iter Monte-Carlo iterations of ALL replicas without returning to the caller -- the body of
@@ -231,7 +243,7 @@ int drna_mc_run(drna_engine *e, int R, int L, int n_iter, const char *target, co
                 const int32_t *snake_nodes, const int32_t *snake_nstates, const char *snake_states,
                 const int32_t *shelf_index, int n_shelves, double tm_max, double tm_min, int targeted, const double *temps,
                 double Lconst, int n_terms, const int32_t *term_id, const double *term_w, uint32_t flags,
-                uint64_t *rng_state, char *seqs, char *mfe_ss, double *score, double *mcc1, double *Epf, double *Ed,
+                uint32_t *rng_state, char *seqs, char *mfe_ss, double *score, double *mcc1, double *Epf, double *Ed,
                 int64_t *counters, char *best_seq, char *best_ss, double *best);
 
 #ifdef __cplusplus

@@ -5,9 +5,11 @@
  * Each function names the reference call it stands for (reference = /root/reference, DesiRNA)
  * and the ViennaRNA 2.6.4 routine whose published algorithm it restates.
  */
+#define _GNU_SOURCE
 #include "oracle.h"
 
 #include <math.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1112,6 +1114,30 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
   if (threads > 0) omp_set_num_threads(threads);
 #else
   (void)threads;
+#endif
+  /* bind OpenMP thread t to the t-th CPU of the process's affinity mask (taken once, before any thread is bound): without
+   * it the threads of a share-limited lease pile onto a few cores and the all-cores figure of the CPU baseline is not a
+   * statement about the cores (OMP_PROC_BIND cannot be used: set in the environment it would also bind the caller's
+   * main thread, i.e. the Python process driving the GPU) */
+#if defined(_OPENMP) && defined(__linux__)
+  {
+    static cpu_set_t base;
+    static int have_base = 0;
+    if (!have_base) { have_base = sched_getaffinity(0, sizeof base, &base) == 0 ? 1 : -1; }
+    if (have_base == 1 && threads > 1) {
+      int ncpu = CPU_COUNT(&base);
+#pragma omp parallel
+      {
+        int t = omp_get_thread_num() % (ncpu > 0 ? ncpu : 1), seen = 0;
+        for (int c = 0; c < CPU_SETSIZE; c++)
+          if (CPU_ISSET(c, &base) && seen++ == t) {
+            cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one);
+            if (omp_get_thread_num() != 0) sched_setaffinity(0, sizeof one, &one);   /* thread 0 is the caller: left alone */
+            break;
+          }
+      }
+    }
+  }
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
   for (int r = 0; r < R; r++) {

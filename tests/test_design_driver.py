@@ -37,6 +37,40 @@ class OracleScorer:
         return out
 
 
+class OracleEngine:
+    """Duck-typed stand-in for engine.Engine in run_design_fast's per-iteration loop (native_loop=False), numbers from the
+    CPU oracle: lets the sharded fast driver (native proposer + Metropolis + MT19937 streams) run without a GPU (tests only)."""
+    TERM_IDS = {}                                  # no drna_mc_run here: forces the per-iteration loop
+
+    def __init__(self, oracle):
+        self.o, self.targets = oracle, []
+
+    def set_targets(self, targets):
+        self.targets = list(targets)
+
+    def score_batch_arrays(self, seqs_u8, flags=0):
+        import numpy as np
+        seqs = [bytes(r).decode() for r in seqs_u8]
+        Epf, Emfe, ss, Ed = self.o.score_batch(seqs, self.targets, threads=4)
+        return Epf, Emfe, np.frombuffer("".join(ss).encode(), dtype=np.uint8).reshape(len(seqs), -1).copy(), Ed
+
+
+def test_fast_driver_equals_python_driver_with_oracle(oracle):
+    """For a fixed seed the batched driver (native proposer with the reference's MT19937 streams, native Metropolis) and the
+    per-replica Python driver walk the same trajectory: same records after every exchange step, same counters."""
+    inp = SimpleNamespace(name="ete1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    sc = OracleScorer(oracle, ETE1, parse_scoring_functions("Ed-Epf:1.0"))
+    a = design.run_design(inp, replicas=6, exchange=15, steps=4, seed=9, scorer=sc)
+    b = design.run_design_fast(inp, replicas=6, exchange=15, steps=4, seed=9, engine=OracleEngine(oracle), native_loop=False)
+    assert [r["sequence"] for r in a["simulation_data"]] == [r["sequence"] for r in b["simulation_data"]]
+    assert [r["temp_shelf"] for r in a["simulation_data"]] == [r["temp_shelf"] for r in b["simulation_data"]]
+    assert [r["sim_step"] for r in b["simulation_data"][-6:]] == [4 * 15] * 6          # stats.step = global_step * RE_attempt
+    for k in ("acc_mc", "acc_mc_better", "rej_mc", "acc_re", "rej_re", "scored"):
+        assert a["stats"][k] == b["stats"][k], k
+    assert a["best"].sequence == b["best"].sequence and abs(a["best"].scoring_function - b["best"].scoring_function) < 1e-9
+
+
 def test_problem_constraints_and_moves():
     p = design.DesignProblem("((((....))))..", "NNNSNNNNWNNNNA")
     assert p.allowed[13] == ["A"] and 13 not in p.mutable
@@ -133,7 +167,7 @@ def test_native_proposals_respect_constraints(hk):
     seq = p.initial_sequence(random.Random(2))
     cur = np.tile(np.frombuffer(seq.encode(), dtype=np.uint8), (R, 1)).copy()
     ss = np.tile(np.frombuffer(("." * len(target)).encode(), dtype=np.uint8), (R, 1)).copy()
-    rng = np.arange(R, dtype=np.uint64)
+    rng = hk.rng_seed(np.arange(R))
     changed = 0
     for it in range(60):
         out = hk.propose(target, amask, cur, ss, np.zeros(R, dtype=np.int32), R, 0.7, 0.0, True, rng)
@@ -148,19 +182,64 @@ def test_native_proposals_respect_constraints(hk):
         cur = out
     assert changed > 0.8 * 60 * R
     # two replicas with the same stream state and the same inputs make the same move
-    rng2 = np.array([7, 7], dtype=np.uint64)
+    rng2 = hk.rng_seed([7, 7])
     o2 = hk.propose(target, amask, cur[:2] * 0 + cur[0], ss[:2], np.zeros(2, dtype=np.int32), R, 0.7, 0.0, True, rng2)
     assert (o2[0] == o2[1]).all()
 
 
+def test_native_rng_is_cpythons_mersenne_twister(hk):
+    """drna_rng_seed / drna_rng_random against CPython's random.seed(int) / random.random() (the reference's worker streams,
+    utils/replica_exchange_monte_carlo.py:227-228), including a seed above 2^32 and the refill of the state after 624 words."""
+    import numpy as np
+    seeds = [0, 1, 2, 63, 2137, 2 ** 31, 2 ** 32 + 5, 2 ** 63 + 11]
+    st = hk.rng_seed(seeds)
+    pys = [random.Random(s) for s in seeds]
+    for _ in range(700):
+        got = hk.rng_random(st)
+        assert list(got) == [p.random() for p in pys]
+
+
+def test_native_proposals_match_recorded_reference_proposals(hk):
+    """The 600 single-strand proposals recorded from the reference's mutate_sequence (tests/golden/host_golden.json, same
+    vectors as tests/test_host_golden.py::test_proposals_same_position_and_draws): the native proposer seeded like the
+    reference's worker must consume the same draws (next random() equal) and produce the same sequence, with the same
+    exemptions as the Python mirror (second letter of a pair move / snake state order depend on str-set order)."""
+    import json, os
+    import numpy as np
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_golden.json")))
+    n = n_exact = 0
+    probs = {}
+    for c in gold["proposals"]:
+        if c.get("oligo_state", "none") != "none":
+            continue                                  # two strands run through the Python driver
+        d = gold["inputs"][c["input"]]
+        key = c["input"]
+        if key not in probs:
+            probs[key] = design.DesignProblem(d["sec_struct"], d["seq_restr"], d["alt_sec_structs"])
+        p = probs[key]
+        st = hk.rng_seed([c["seed"]])
+        cur = np.frombuffer(c["sequence"].encode(), dtype=np.uint8).reshape(1, -1).copy()
+        ss = np.frombuffer(c["mfe_ss"].encode(), dtype=np.uint8).reshape(1, -1).copy()
+        out = hk.propose_alt(p, cur, ss, np.array([c["shelf"]], dtype=np.int32), c["n_shelves"], 0.7, 0.0, True, st)
+        mine = out[0].tobytes().decode()
+        assert hk.rng_random(st)[0] == c["next_random"], c          # same number of draws consumed
+        # and the same proposal as the Python mirror, letter for letter
+        rr = random.Random(c["seed"])
+        pos = p.mutation_position(c["mfe_ss"], c["shelf"], c["n_shelves"], 0.7, 0.0, True, rr)
+        assert mine == p.mutate(c["sequence"], pos, rr), c
+        n += 1
+        n_exact += mine == c["proposed"]
+    assert n == 600 and n_exact > n // 2
+
+
 def test_native_metropolis_semantics(hk):
     import numpy as np
-    rng = np.arange(4, dtype=np.uint64)
+    rng = hk.rng_seed(np.arange(4))
     before = rng.copy()
     acc, better = hk.metropolis([1.0, 1.0, 1.0, 1.0], [0.5, 1.0, 1.0 + 1e-9, 50.0], [10.0, 10.0, 1e9, 10.0], rng)
     assert list(acc[:2]) == [True, True] and list(better) == [True, True, False, False]
     assert acc[2] and not acc[3]                     # tiny uphill at huge T is accepted, huge uphill is not
-    assert (rng[:2] == before[:2]).all() and (rng[2:] != before[2:]).all()   # a draw only when the mutant is worse
+    assert (rng[:2] == before[:2]).all() and (rng[2:] != before[2:]).any(axis=1).all()   # a draw only when the mutant is worse
 
 
 @pytest.mark.gpu
@@ -203,7 +282,7 @@ def test_native_snake_proposals(hk):
     _snake_invariants(p, seq)
     cur = np.tile(np.frombuffer(seq.encode(), dtype=np.uint8), (R, 1)).copy()
     ss = np.tile(np.frombuffer(("." * p.n).encode(), dtype=np.uint8), (R, 1)).copy()
-    rng = np.arange(R, dtype=np.uint64)
+    rng = hk.rng_seed(np.arange(R))
     moved_snake = 0
     for it in range(40):
         out = hk.propose_alt(p, cur, ss, np.zeros(R, dtype=np.int32), R, 0.7, 0.0, True, rng)
@@ -270,3 +349,22 @@ def test_native_mc_loop_equals_python_loop_on_gpu(eterna_targets):
     for k in ("acc_mc", "acc_mc_better", "rej_mc", "acc_re", "rej_re", "scored"):
         assert a["stats"][k] == b["stats"][k], k
     assert [r["sequence"] for r in a["simulation_data"]] == [r["sequence"] for r in b["simulation_data"]]
+    # ... and what the per-replica Python driver (random.Random(replica) streams, ReplicaScorer) does for the same seed
+    c = design.run_design(inp, replicas=16, exchange=25, steps=3, seed=7, scoring_f="Ed-Epf:0.9")
+    assert [r["sequence"] for r in a["simulation_data"]] == [r["sequence"] for r in c["simulation_data"]]
+    assert [r["temp_shelf"] for r in a["simulation_data"]] == [r["temp_shelf"] for r in c["simulation_data"]]
+    for k in ("acc_mc", "acc_mc_better", "rej_mc", "acc_re", "rej_re", "scored"):
+        assert a["stats"][k] == c["stats"][k], k
+
+
+@pytest.mark.gpu
+def test_avoid_oligomerization_design_run_builds_its_own_engines():
+    """-oa on through run_design WITHOUT an injected engine: every candidate is also folded against itself (s & s, 2 L
+    nucleotides), which needs an engine sized for 2 L (reference utils/energy_scores.py:411-418)."""
+    tg = "((((((.((((((((....))))).)).).))))))"
+    inp = SimpleNamespace(name="oa", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    res = design.run_design(inp, replicas=4, exchange=5, steps=2, seed=4, oligo="on")
+    assert res["stats"]["scored"] == 4 + 2 * 5 * 4
+    for r in res["simulation_data"]:
+        assert 0.0 <= r["oligo_fraction"] <= 1.0

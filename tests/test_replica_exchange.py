@@ -132,6 +132,145 @@ def test_sharded_design_run_gloo_world2(tmp_path):
     assert outs[0]["scored"] == outs[1]["scored"] == 3 + 3 * 10 * 3
 
 
+def _run_ranks(script, world=2, timeout=900):
+    import json
+    port = _free_port()
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, out
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    return outs
+
+
+def test_sharded_unseeded_run_and_collective_stop_gloo_world2(tmp_path):
+    """with the default seed (0 = unseeded) every rank used to seed its own main stream, and the loop exits
+    (time limit, stop-when-solved) were rank-local, so one rank could leave while the other blocked in the all-gather.
+    Now rank 0's seed is broadcast and the stop decision comes out of the gathered flags: both ranks end after the same
+    number of exchange steps with the same ladder, although only one of them may hold the solved replica."""
+    script = tmp_path / "worker_stop.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from types import SimpleNamespace
+        import torch.distributed as dist
+        from desirna_amd import design, params
+        from desirna_amd.energy_scores import parse_scoring_functions
+        from desirna_amd.replica_exchange import ReplicaShards
+        from oracle.pyoracle import Oracle
+        from tests.test_design_driver import OracleScorer, ETE1
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        inp = SimpleNamespace(name="e1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+        sc = OracleScorer(Oracle(params.load_blob()), ETE1, parse_scoring_functions("Ed-Epf:1.0"))
+        res = design.run_design(inp, replicas=5, exchange=20, steps=40, seed=0, scorer=sc, stop_when_solved=True,
+                                shards=ReplicaShards(5, rank, world))
+        print(json.dumps({"rank": rank, "steps": res["steps"], "temps": res["temps"], "solved": res["solved"],
+                          "best": res["best"].sequence, "first": res["simulation_data"][0]["sequence"]}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    outs = _run_ranks(script)
+    assert outs[0]["steps"] == outs[1]["steps"] < 40 and outs[0]["solved"] and outs[1]["solved"]
+    assert outs[0]["temps"] == outs[1]["temps"] and outs[0]["first"] == outs[1]["first"]       # same seed on both ranks
+    assert outs[0]["best"] == outs[1]["best"]                                                  # best of the whole job
+
+
+def test_sharded_fast_driver_equals_single_rank_gloo_world2(tmp_path, oracle):
+    """run_design_fast with shards (native proposer / Metropolis with the reference's per-replica MT19937 streams, oracle-
+    backed engine stub): two ranks together hold every replica once, end with the same ladder, and reproduce the records
+    of the unsharded run replica by replica -- ONE all-gather per exchange step."""
+    script = tmp_path / "worker_fast.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from types import SimpleNamespace
+        import torch.distributed as dist
+        from desirna_amd import design, params
+        from desirna_amd.replica_exchange import ReplicaShards
+        from oracle.pyoracle import Oracle
+        from tests.test_design_driver import OracleEngine, ETE1
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        calls = [0]
+        orig = dist.all_gather_into_tensor
+        def counted(*a, **k):
+            calls[0] += 1
+            return orig(*a, **k)
+        dist.all_gather_into_tensor = counted
+        inp = SimpleNamespace(name="e1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+        res = design.run_design_fast(inp, replicas=7, exchange=12, steps=3, seed=21, engine=OracleEngine(Oracle(params.load_blob())),
+                                     native_loop=False, shards=ReplicaShards(7, rank, world))
+        print(json.dumps({"rank": rank, "local": res["local"], "temps": res["temps"], "gathers": calls[0],
+                          "recs": [[r["replica_num"], r["sim_step"], r["sequence"], r["temp_shelf"]] for r in res["simulation_data"]],
+                          "best": res["best"].sequence, "acc_re": res["stats"]["acc_re"]}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    outs = _run_ranks(script)
+    from types import SimpleNamespace
+    from desirna_amd import design
+    from tests.test_design_driver import OracleEngine, ETE1
+    inp = SimpleNamespace(name="e1", sec_struct=ETE1, seq_restr="N" * 16, seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+    one = design.run_design_fast(inp, replicas=7, exchange=12, steps=3, seed=21, engine=OracleEngine(oracle), native_loop=False)
+    assert sorted(outs[0]["local"] + outs[1]["local"]) == list(range(7))
+    assert outs[0]["temps"] == outs[1]["temps"] == one["temps"]
+    assert outs[0]["gathers"] == outs[1]["gathers"] == 3 + 1          # one per exchange step (+ the start-up flag exchange)
+    want = sorted([r["replica_num"], r["sim_step"], r["sequence"], r["temp_shelf"]] for r in one["simulation_data"])
+    assert sorted(outs[0]["recs"] + outs[1]["recs"]) == want
+    assert outs[0]["best"] == outs[1]["best"] == one["best"].sequence and outs[0]["acc_re"] == one["stats"]["acc_re"]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_sharded_native_fast_driver_two_ranks_one_gpu(tmp_path, eterna_targets):
+    """The production fast path (drna_mc_run: the whole inner loop native, scoring on the GPU) with the replicas of one
+    design sharded over two ranks that share this box's single GPU (gloo rehearsal; RCCL needs one GPU per rank): union of
+    replicas, identical ladders, one all-gather per exchange step, and the records / best of the unsharded run
+    (reference utils/replica_exchange_monte_carlo.py:233-271, :113-173)."""
+    tg = eterna_targets["eteV1_92.txt"]
+    script = tmp_path / "worker_gpu.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from types import SimpleNamespace
+        import torch.distributed as dist
+        from desirna_amd import design
+        from desirna_amd.replica_exchange import ReplicaShards
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        calls = [0]
+        orig = dist.all_gather_into_tensor
+        def counted(*a, **k):
+            calls[0] += 1
+            return orig(*a, **k)
+        dist.all_gather_into_tensor = counted
+        tg = %r
+        inp = SimpleNamespace(name="e92", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+        res = design.run_design_fast(inp, replicas=16, exchange=20, steps=3, seed=5, shards=ReplicaShards(16, rank, world))
+        print(json.dumps({"rank": rank, "local": res["local"], "temps": res["temps"], "gathers": calls[0],
+                          "recs": [[r["replica_num"], r["sim_step"], r["sequence"], r["temp_shelf"]] for r in res["simulation_data"]],
+                          "best": res["best"].sequence, "acc_re": res["stats"]["acc_re"], "scored": res["stats"]["scored"]}))
+        dist.destroy_process_group()
+    """ % (ROOT, tg)))
+    outs = _run_ranks(script)
+    from types import SimpleNamespace
+    from desirna_amd import design
+    inp = SimpleNamespace(name="e92", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None, alt_sec_structs=None)
+    one = design.run_design_fast(inp, replicas=16, exchange=20, steps=3, seed=5)
+    assert sorted(outs[0]["local"] + outs[1]["local"]) == list(range(16))
+    assert outs[0]["temps"] == outs[1]["temps"] == one["temps"]
+    assert outs[0]["gathers"] == outs[1]["gathers"] == 3 + 1
+    want = sorted([r["replica_num"], r["sim_step"], r["sequence"], r["temp_shelf"]] for r in one["simulation_data"])
+    assert sorted(outs[0]["recs"] + outs[1]["recs"]) == want
+    assert outs[0]["best"] == outs[1]["best"] == one["best"].sequence
+    assert outs[0]["scored"] + outs[1]["scored"] == one["stats"]["scored"] and outs[0]["acc_re"] == one["stats"]["acc_re"]
+
+
 def test_shard_puzzles_balances_cubes():
     from desirna_amd.replica_exchange import shard_puzzles
     lengths = [400, 12, 36, 200, 104, 104, 380, 16, 90, 250]
