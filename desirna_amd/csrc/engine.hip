@@ -88,6 +88,9 @@ struct drna_engine {
     hipError_t _e = (call);                                                                \
     if (_e != hipSuccess) {                                                                \
       e->err = std::string(#call) + ": " + hipGetErrorString(_e);                          \
+      /* kernels of this call may already be enqueued on the engine's other streams: the next call assumes idle   */ \
+      /* streams (it rewrites h_status and the workspaces), so drain the device before handing the error back     */ \
+      (void)hipDeviceSynchronize();                                                        \
       return DRNA_ERR_DEVICE;                                                              \
     }                                                                                      \
   } while (0)
@@ -1069,7 +1072,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
   std::vector<int32_t> pEmfe(R), pEd((size_t)R * nt);
   std::vector<unsigned char> acc(R), better(R);
   std::vector<int> pr(L), pq(L);
-  if (!pair_table(target, L, pr.data())) return DRNA_ERR_STRUCTURE;
+  if (!pair_table(target, L, pr.data())) { e->err = "drna_mc_run: unbalanced target structure"; return DRNA_ERR_STRUCTURE; }
   for (int it = 0; it < n_iter; it++) {
     int rc = propose_impl(R, L, target, partner, allowed_mask, n_snakes > 0 ? snake_of : nullptr, snake_off, snake_nodes,
                           snake_nstates, snake_states, seqs, mfe_ss, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state,
@@ -1080,7 +1083,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
     if (rc != DRNA_OK) return rc;
     for (int r = 0; r < R; r++) {
       // SimScore of the proposal's structure against the target (utils/sim_score.py:62-147)
-      if (!pair_table(pss.data() + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
+      if (!pair_table(pss.data() + (size_t)r * L, L, pq.data())) { e->err = "drna_mc_run: unbalanced MFE structure from the engine"; return DRNA_ERR_STRUCTURE; }
       long tp = 0, fp = 0, fn = 0, tn = 0;
       for (int i = 0; i < L; i++) {
         if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }

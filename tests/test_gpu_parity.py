@@ -508,3 +508,99 @@ def test_negative_design_scoring(eng400, oracle, traj_golden, example_inputs):
         else:
             assert sc.subopt_e == 0 and sc.scoring_function == sc.edesired_minus_Epf
     assert sum(sc.mcc == 0 for sc in res) == len(solved)
+
+
+# ---- BASELINE configs 4 and 5 at their FULL sizes (round-1 verdict, item 8): the sizes where workspace, queueing and the
+# mix of LDS-resident and general kernels in one call matter
+
+def test_config4_full_size_3200_sequences(oracle, eterna_solutions):
+    """Config 4 as stated: the 100 Eterna100-V1 puzzles x 32 mutated replicas = 3,200 sequences (12 ... 400 nt) in ONE
+    ragged call.  Size-independent properties on every entry (E(MFE structure) == MFE energy through the oracle's
+    evaluation for a sample, Epf <= Emfe, repeatability bit for bit) and 64 random entries against the oracle."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(4004)
+    rows = eterna_solutions
+    seqs, tof = [], []
+    for p, r in enumerate(rows):
+        for _ in range(32):
+            s = list(r["sequence"])
+            for pos in rng.choice(len(s), size=min(3, len(s)), replace=False):
+                s[pos] = "ACGU"[rng.integers(4)]
+            seqs.append("".join(s))
+            tof.append(p)
+    assert len(seqs) == 3200
+    big = E.Engine(max_R=3200, max_L=400, device=0)
+    try:
+        big.set_targets_ragged([r["structure"] for r in rows])
+        out = big.score_ragged(seqs, tof)
+        again = big.score_ragged(seqs, tof)
+        assert out["mfe_ss"] == again["mfe_ss"] and (out["Emfe"] == again["Emfe"]).all() and (out["Ed"] == again["Ed"]).all()
+        assert (out["Epf"].view(np.int64) == again["Epf"].view(np.int64)).all()
+        assert (out["Epf"] <= out["Emfe"] / 100.0 + 1e-9).all()
+        for k in range(len(seqs)):
+            assert len(out["mfe_ss"][k]) == len(seqs[k]) and out["mfe_ss"][k].count("(") == out["mfe_ss"][k].count(")")
+        for k in rng.choice(len(seqs), size=64, replace=False):
+            k = int(k)
+            ss, e = oracle.mfe(seqs[k])
+            assert out["mfe_ss"][k] == ss and int(out["Emfe"][k]) == e, (k, rows[tof[k]]["name"])
+            assert abs(float(out["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE
+            assert int(out["Ed"][k]) == oracle.eval_structure(seqs[k], rows[tof[k]]["structure"])
+            assert oracle.eval_structure(seqs[k], ss) == e
+    finally:
+        big.close()
+
+
+def test_config5_full_size_R128_L400_pk_alts_edef(eng400, oracle, eterna_targets):
+    """Config 5 as stated: L=400 target, R=128, pk heuristic, two alternative targets and the ensemble defect, all in one
+    test on one engine: properties on all 128 entries, 6 entries against the oracle (a 400-mer with up to four fills
+    takes the oracle a good fraction of a second)."""
+    from desirna_amd import engine as E
+    tg = eterna_targets["eteV1_53.txt"]
+    alts = [eterna_targets["eteV1_22.txt"], eterna_targets["eteV1_63.txt"]]
+    L = len(tg)
+    rng = np.random.default_rng(5128)
+    seqs = [_rand(rng, L) for _ in range(120)] + [_rand(rng, L, "GGCCAU") for _ in range(8)]
+    eng400.set_targets([tg] + alts)
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL | E.NEED_PK
+    out = eng400.score_batch(seqs, flags)
+    ed = eng400.ensemble_defect(seqs)
+    again = eng400.score_batch(seqs, flags)
+    assert out["mfe_ss"] == again["mfe_ss"] and (out["Ed"] == again["Ed"]).all()
+    assert (out["Epf"].view(np.int64) == again["Epf"].view(np.int64)).all()
+    assert ((0.0 <= ed) & (ed <= 1.0)).all() and (out["Epf"] <= out["Emfe"] / 100.0 + 1e-9).all()
+    for k in range(128):
+        s = out["mfe_ss"][k]
+        for o, c in ("()", "[]", "<>", "{}"):
+            assert s.count(o) == s.count(c)
+        plain = "".join(ch if ch in "()" else "." for ch in s)
+        # the pk-annotated string's '(' ')' layer is the unconstrained MFE structure: its energy is the MFE energy
+        if k < 12:
+            assert oracle.eval_structure(seqs[k], plain) == int(out["Emfe"][k])
+    for k in (0, 1, 60, 119, 120, 127):
+        ss, e = oracle.mfe(seqs[k])
+        assert out["mfe_ss"][k] == oracle.pk_struct(seqs[k], ss) and int(out["Emfe"][k]) == e
+        assert abs(float(out["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE
+        for t, st in enumerate([tg] + alts):
+            assert int(out["Ed"][k, t]) == oracle.eval_structure(seqs[k], st)
+        assert abs(ed[k] - oracle.ensemble_defect(seqs[k], tg)) < 1e-10
+
+
+def test_pf_range_error_code():
+    """DRNA_ERR_PF_RANGE (-6): a parameter blob whose stacking energies are -40 kcal/mol drives the partition function of a
+    36-nt hairpin beyond fp64 (Z ~ e^840); the engine must report it instead of returning inf / nan (LDS-resident and
+    general kernel)."""
+    from desirna_amd import engine as E, params
+    blob = np.array(params.load_blob(), dtype=np.int32, copy=True)
+    blob[3:3 + 64] = np.where(blob[3:3 + 64] < 0, -4000, blob[3:3 + 64])       # stack[8][8] follows the 3 header words
+    seq = "GGGGGGGGGGGGGGGGAAAACCCCCCCCCCCCCCCC"
+    for max_L, s in ((36, seq), (260, seq + "A" * 224)):
+        eng = E.Engine(max_R=2, max_L=max_L, device=0, params=blob)
+        try:
+            eng.set_targets(["." * len(s)])
+            with pytest.raises(E.EngineError) as ei:
+                eng.score_batch([s, s], E.NEED_PF)
+            assert ei.value.code == -6
+            ok = eng.score_batch(["A" * len(s)] * 2, E.NEED_PF)               # the engine stays usable
+            assert np.isfinite(ok["Epf"]).all()
+        finally:
+            eng.close()
