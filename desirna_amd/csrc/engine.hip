@@ -19,6 +19,7 @@
 #include "fold_mfe.hpp"
 #include "fold_cofold.hpp"
 #include "fold_mfe_lds.hpp"
+#include "fold_mfe_dual.hpp"
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
@@ -80,6 +81,12 @@ struct drna_engine {
   int32_t *hm_Emfe = nullptr, *dm_Emfe = nullptr, *hm_Ed = nullptr, *dm_Ed = nullptr;
   size_t hm_Ed_cap = 0;
   bool zero_copy = true;
+  // two-workgroup kernels (small batches: 4 R <= CUs, n <= 200): exchange rows and flags, allocated on first use
+  bool dual = true;               // DRNA_DUAL=0 turns them off
+  int dual_cap = 0;               // sequences the exchange buffers hold
+  int dual_epoch = 0;             // grows by one per launch; flags are never reset (fold_common.hpp, DualLink)
+  int* d_dflags = nullptr;        // [2 kernels][dual_cap][64]
+  int32_t *d_xs = nullptr, *d_xa_mfe = nullptr, *d_xb_mfe = nullptr;
   std::string err;
 };
 
@@ -123,6 +130,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   e->cus = prop.multiProcessorCount;
+  if (const char* dv = getenv("DRNA_DUAL")) e->dual = atoi(dv) != 0;
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
   HIP_TRY(upload(&e->d_plan, &e->H.plan, 1));
@@ -180,7 +188,8 @@ extern "C" void drna_destroy(drna_engine* e) {
   if (!e) return;
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
-                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss};
+                  e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss,
+                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -258,6 +267,27 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   HIP_TRY(hipSetDevice(e->device));
   const int ld = L + 2;
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
+  // small batches leave most CUs idle with one workgroup per fold (R = 64: 128 workgroups on 256 CUs): fold every sequence
+  // with a main and a helper workgroup instead (fold_mfe_dual.hpp).  Both folds of the call then fill the chip exactly, so
+  // this needs 4 R <= CUs; larger batches keep the one-workgroup kernels, which saturate the chip by themselves
+  const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4 * R <= e->cus;
+  if (use_dual) {
+    if (e->dual_cap < R) {
+      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
+      for (void* b : old) if (b) (void)hipFree(b);
+      e->d_dflags = nullptr; e->d_xs = nullptr; e->d_xa_mfe = nullptr; e->d_xb_mfe = nullptr;
+      e->dual_cap = 0;
+      const size_t rows = (size_t)2 * (MFE_FAST_NMAX + 2) * XP;
+      HIP_TRY(hipMalloc((void**)&e->d_dflags, (size_t)2 * R * 64 * sizeof(int)));
+      HIP_TRY(hipMemset(e->d_dflags, 0, (size_t)2 * R * 64 * sizeof(int)));
+      HIP_TRY(hipMalloc((void**)&e->d_xs, (size_t)R * 256 * sizeof(int32_t)));
+      HIP_TRY(hipMalloc((void**)&e->d_xa_mfe, (size_t)R * rows * sizeof(int32_t)));
+      HIP_TRY(hipMalloc((void**)&e->d_xb_mfe, (size_t)R * rows * sizeof(int32_t)));
+      e->dual_cap = R;
+      e->dual_epoch = 0;
+    }
+    e->dual_epoch = (int)((unsigned)e->dual_epoch + 1u);           // never reset: flag compares are wrap-safe
+  }
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
   // previous call is enqueued first
@@ -284,7 +314,16 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
     a.Emfe = d_Emfe; a.ss = d_mfe_ss; a.status = e->d_status;
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
-    if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
+    if (use_dual) {
+      DualLink lk;
+      lk.flagA = e->d_dflags; lk.flagB = e->d_dflags;
+      lk.xs = e->d_xs; lk.xa = e->d_xa_mfe; lk.xb = e->d_xb_mfe; lk.epoch = e->dual_epoch;
+#ifdef DRNA_DUALDBG
+      lk.dbg = reinterpret_cast<long long*>(e->d_ws_mfe + 2 * (size_t)ld * ld + 8192);  // table 2 of sequence 0's workspace is unused by the LDS kernels
+      (void)hipMemsetAsync(lk.dbg, 0, 64 * 64 * sizeof(long long), e->s_mfe);
+#endif
+      hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_mfe, a, lk);
+    } else if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
       hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_mfe, a);
     else if (e->nt == 256) launch_mfe<256>(a, R, e->s_mfe);
     else if (e->nt == 512) launch_mfe<512>(a, R, e->s_mfe);
@@ -664,6 +703,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     char buf[160];
     snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
                               : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"
+                              : st == ST_SYNC ? "sequence %d: the two workgroups of the fold lost each other (wait expired)"
                                                   : "sequence %d: traceback could not reproduce a table value", r);
     e->err = buf;
     return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;
@@ -858,6 +898,7 @@ extern "C" int drna_cofold_batch(drna_engine* e, int R, int L, int cut, const ch
     char buf[160];
     snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
                               : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"
+                              : st == ST_SYNC ? "sequence %d: the two workgroups of the fold lost each other (wait expired)"
                                                   : "sequence %d: traceback could not reproduce a table value", r);
     e->err = buf;
     return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;

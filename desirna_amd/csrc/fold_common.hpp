@@ -15,7 +15,7 @@ constexpr int GRES = 28;          // 27 live entries + 1 spare
 enum : int { TW_LIVE = 0, TW_BIRTH = 1, TW_KILL = 2, TW_DEAD = 3 };   // flag in the low bits of a tower-table word
 
 // kernel status codes (per sequence)
-enum : int { ST_OK = 0, ST_BAD_CHAR = 1, ST_TRACEBACK = 2, ST_PF_RANGE = 3 };
+enum : int { ST_OK = 0, ST_BAD_CHAR = 1, ST_TRACEBACK = 2, ST_PF_RANGE = 3, ST_SYNC = 4 };
 
 // Ragged batches (drna_score_ragged): sequences of different lengths in one launch.  idx maps a workgroup to its sequence
 // (the host sorts by length, longest first, and splits the list between the LDS-resident and the general kernels), len is
@@ -25,6 +25,67 @@ struct Ragged {
   const int* len = nullptr;
   const int* off = nullptr;
 };
+
+// ---- two-workgroup kernels (fold_mfe_dual.hpp, fold_pf_dual.hpp): one sequence is folded by a MAIN workgroup (finalize,
+// towers, near shapes) and a HELPER workgroup on another CU (multiloop splits, far shapes) that runs a few diagonals
+// behind on rows the main one publishes.  Cross-CU visibility follows the CDNA4 guide: payload by agent-scope (sc1,
+// write-through / L1-bypassing) stores and loads, every storing wave drains vmcnt, workgroup barrier, then ONE lane stores
+// the flag; the consumer polls the flag from one lane with sc1 loads and loads the payload only after it has matched.
+// Flag values grow monotonically over diagonals, pseudoknot rounds and calls: ((epoch * 8 + round) << 10) + diagonal,
+// compared wrap-safe, so nothing is ever reset; DONE closes a call.  Every wait is bounded (ST_SYNC on expiry).
+// The helper works on diagonal D with rows <= D - DLAG only: multiloop split points further than KEDGE from either end of the
+// range, loop shapes whose inner pair is at least DLAG diagonals back.  The slack this buys (DLAG - 3 steps of the main
+// workgroup) has to cover the round trip through L2 / fabric (~3 us) plus the helper's own step.
+constexpr int DLAG = 8, KEDGE = DLAG - 5;
+constexpr int XP = 224;           // row pitch of the exchange tables for n <= 200: rows are whole 128-byte lines
+struct DualLink {
+  int* flagA = nullptr;           // written by the main workgroup: base + last published diagonal (base + 3 = round prologue done)
+  int* flagB = nullptr;           // written by the helper: base + last diagonal whose results are published
+  int32_t* xs = nullptr;          // main -> helper: pairing codes Sp[0 .. n+1] of the round (4 = masked)
+  void* xa = nullptr;             // main -> helper rows (MFE: wring word, fML; PF: see fold_pf_dual.hpp)
+  void* xb = nullptr;             // helper -> main rows (MFE: split minima, far-shape minima)
+  long long* dbg = nullptr;       // diagnostic builds (-DDRNA_DUALDBG): cycle counters, 64 words per sequence
+  int base = 0;                   // ((epoch * 8 + round) << 10)
+  int epoch = 0;
+};
+__device__ __forceinline__ int dual_base(int epoch, int round) { return (int)((((unsigned)epoch * 8u + (unsigned)round) << 10)); }   // wraps: compares are wrap-safe
+__device__ __forceinline__ int dual_done(int epoch) { return (int)((((unsigned)epoch * 8u + 7u) << 10) + 1023u); }
+__device__ __forceinline__ bool flag_ge(int v, int target) { return (int)((unsigned)v - (unsigned)target) >= 0; }
+
+#ifdef DRNA_EMU
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+__device__ __forceinline__ void drain_vmem() {}
+__device__ __forceinline__ void spin_pause() { sched_yield(); }
+#else
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+#endif
+// wait until at most N of the wave's vector-memory operations are outstanding (they retire in issue order)
+template <int N>
+__device__ __forceinline__ void stores_in_flight() {
+#ifndef DRNA_EMU
+  if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+constexpr int SPIN_LIMIT = 1 << 18;
+#ifdef DRNA_DUALDBG
+#define DDBG(stmt) do { stmt; } while (0)
+#else
+#define DDBG(stmt) do { } while (0)
+#endif
+// all lanes of the calling wave poll the same word (one request); returns false when the wait expired
+__device__ __forceinline__ bool wait_flag_wave(const int* flag, int target) {
+  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+    if (flag_ge(__builtin_amdgcn_readfirstlane(ld_agent(flag)), target)) return true;
+    spin_pause();
+  }
+  return false;
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }

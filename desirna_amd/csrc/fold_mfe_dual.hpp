@@ -1,0 +1,204 @@
+// fold_mfe_dual.hpp -- two-workgroup form of the LDS-resident MFE fill (n <= MFE_FAST_NMAX), used when the batch is small
+// enough that half of the chip would otherwise idle (R = 64 replicas: 2 folds x 64 workgroups on 256 CUs).  Same recursions
+// and results, bit for bit, as mfe_lds_kernel (reference utils/energy_scores.py:151).
+//
+// Roles (workgroups 2r and 2r+1 of the grid fold sequence r):
+//   MAIN   (mfe_lds_body<NT, true>, fold_mfe_lds.hpp): finalize, tower step (generic interior loops), the six NEAR shapes
+//          whose inner pair is at most four diagonals back, exterior column, traceback, pseudoknot rounds.  After every
+//          diagonal it publishes the ring word and the fML value of each cell.
+//   HELPER (mfe_helper, here): multiloop splits (K) and the 115 FAR bulge / 1xn / small shapes (E) of diagonal D, which need
+//          nothing newer than diagonal D-5: it mirrors the published rows into its own LDS (fML triangle, 32-row ring),
+//          runs up to five diagonals behind the main workgroup's finalize and AHEAD of its need (the results of D are
+//          consumed when D is finalized), and publishes two minima per cell and diagonal.
+// Wave roles in the helper: wave 0 INBOUND (waits for the rows of diagonal D-4 and copies them to LDS), wave 1 OUTBOUND (ships the minima of diagonal D-1,
+// drains its stores, raises flagB), wave 2 TABLES (pairable list / staged small-loop energies / shape table of diagonal D+1),
+// waves 3..15 work through the items of diagonal D from a queue.  One workgroup barrier
+// per diagonal; the tables are double-buffered by diagonal parity.  Handshake: DualLink in fold_common.hpp.
+#pragma once
+#include "fold_mfe_lds.hpp"
+
+namespace drna {
+
+template <int NT>
+struct MfeHelperSmem {
+  static constexpr int RS = MFE_FAST_NMAX + 2;
+  static constexpr int TRI = (MFE_FAST_NMAX - 4) * (MFE_FAST_NMAX - 3) / 2;
+  static constexpr int NSLOT = 4 * WAVE;
+  static constexpr int NL = MFE_FAST_NMAX + 8;
+  static constexpr int XT_STACK = 0, XT_INT11 = 64, XT_MM1N = 64 + 1024, XT_MM23 = 64 + 1024 + 128;
+  int fml[TRI + 8];
+  int wring[33 * RS];
+  int accK[2][NSLOT], accI[2][NSLOT];
+  int xtab[64 + 1024 + 128 + 128];
+  int mm1n[128], mm23[128];
+  int eshape[128], etab[2][128];
+  int plist[2][NL], xe[2][1];       // xe: only named by the shared item code's small-shape branch, which the helper never takes
+  int pcnt[2], qhead[2];
+  int flag, fail;
+  unsigned char S[MFE_FAST_NMAX + 4], Sp[MFE_FAST_NMAX + 4];
+};
+
+template <int NT>
+__device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
+  using SM = MfeHelperSmem<NT>;
+  constexpr int RS = SM::RS;
+  const MfeTables& T = *A.T;
+  const int n = A.L, tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  const int INF = INF_DEV, TermAU = T.TermAU;
+  const int32_t* const xw = reinterpret_cast<const int32_t*>(lk.xa);
+  const int32_t* const xf = xw + (MFE_FAST_NMAX + 2) * XP;
+  int32_t* const xk = reinterpret_cast<int32_t*>(lk.xb);
+  int32_t* const xi = xk + (MFE_FAST_NMAX + 2) * XP;
+
+  // ---- constant tables (same contents as the main workgroup's) and the sequence
+  for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = T.stack[k] - ((k & 7) > 2 ? TermAU : 0);
+  for (int k = tid; k < 1024; k += NT) sm.xtab[SM::XT_INT11 + k] = T.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
+  for (int k = tid; k < 128; k += NT) {
+    sm.mm1n[k] = T.mm1n[k]; sm.mm23[k] = T.mm23[k];
+    sm.xtab[SM::XT_MM1N + k] = T.mm1n[k] - ((k >> 4) > 2 ? TermAU : 0);
+    sm.xtab[SM::XT_MM23 + k] = T.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
+  }
+  mfe_init_eshape(sm, T, tid, NT);
+  for (int k = tid; k < 33 * RS; k += NT) sm.wring[k] = INF * 256;
+  for (int k = tid; k < SM::NSLOT; k += NT)
+    for (int p = 0; p < 2; p++) { sm.accK[p][k] = INF; sm.accI[p][k] = INF; }
+  if (tid == 0) { sm.flag = 0; sm.fail = 0; }
+  __syncthreads();
+  const char* seq = A.seqs + (long long)r * n;
+  for (int k = tid; k < n; k += NT) {
+    const int c = enc_nt(seq[k]);
+    if (c < 0) sm.flag = 1;
+    sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
+  }
+  __syncthreads();
+  if (sm.flag) return;                               // the main workgroup reports the bad character
+  if (tid == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
+  const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + T.ninio);
+
+  // pairable cells of diagonal dn (i | pair info << 8, as in the main workgroup's list) and the far-shape table, rebuilt here
+  // from the sequence; the staged small-loop energies are not needed: every small shape is a NEAR shape
+  auto prepare = [&](const int dn) {
+    const int par = dn & 1, ncell = n - dn;
+    int t[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = c * WAVE + lane + 1;
+      t[c] = i <= ncell ? pair_type(sm.Sp[i], sm.Sp[i + dn]) : 0;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const unsigned long long m = __ballot(t[c] != 0);
+      if (t[c]) {
+        const int i = c * WAVE + lane + 1, j = i + dn;
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < SM::NL) sm.plist[par][pos] = i | ((t[c] * 16 + sm.S[i + 1] * 4 + sm.S[j - 1]) << 8);
+      }
+      cnt += __popcll(m);
+    }
+    mfe_prepare_etab(sm, dn, lane, E_FAR);
+    if (lane == 0) { sm.pcnt[par] = cnt; sm.qhead[par] = 0; }
+  };
+
+  DDBG(if (tid == 0) lk.dbg[15] -= clock64());
+  for (int round = 0; round <= A.pk_rounds; round++) {
+    const int base = dual_base(lk.epoch, round);
+    // ---- the round starts when the main workgroup has published its pairing codes (or ends the call)
+    if (wave == 0) {
+      if (!wait_flag_wave(lk.flagA, base + TURN)) sm.fail = 1;
+      else if (flag_ge(__builtin_amdgcn_readfirstlane(ld_agent(lk.flagA)), dual_done(lk.epoch))) sm.fail = 2;    // no further round
+    }
+    __syncthreads();
+    if (sm.fail) break;
+    for (int k = tid; k <= n + 1; k += NT) sm.Sp[k] = (unsigned char)ld_agent(lk.xs + k);
+    __syncthreads();
+    if (wave == 0 && TURN + 1 < n) prepare(TURN + 1);
+    __syncthreads();
+
+    for (int D = TURN + 1; D <= n; D++) {            // step D = n only ships the last diagonal
+      const int par = D & 1, ncell = n - D;
+      if (wave == 0) {
+        // ---- inbound: rows of diagonal D+1-DLAG (needed from diagonal D+1 on)
+        if (D + 1 < n) {
+          const int dr = D + 1 - DLAG;
+          if (dr > TURN) {
+            DDBG(if (lane == 0) lk.dbg[8] -= clock64());
+            if (!sm.fail && !wait_flag_wave(lk.flagA, base + dr)) sm.fail = 1;
+            DDBG(if (lane == 0) { const long long t = clock64(); lk.dbg[8] += t; lk.dbg[9] -= t; });
+            const int ro = fml_off(dr, n);
+            int vw[4], vf[4];                                    // all eight loads in flight, then the LDS stores
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              const int i = c * WAVE + lane + 1;
+              const bool on = i <= n - dr;
+              vw[c] = on ? ld_agent(xw + dr * XP + i) : 0;
+              vf[c] = on ? ld_agent(xf + dr * XP + i) : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              const int i = c * WAVE + lane + 1;
+              if (i <= n - dr) { sm.wring[(dr & 31) * RS + i] = vw[c]; sm.fml[ro + i - 1] = vf[c]; }
+            }
+            DDBG(if (lane == 0) lk.dbg[9] += clock64());
+          }
+        }
+      } else if (wave == 2) {
+        DDBG(if (lane == 0) lk.dbg[10] -= clock64());
+        if (D + 1 < n) prepare(D + 1);               // tables of the next diagonal (sequence only: no wait)
+        DDBG(if (lane == 0) lk.dbg[10] += clock64());
+      } else if (wave == 1) {
+        // ---- outbound: minima of diagonal D-1 (reset for diagonal D+1), then the flag
+        const int ds = D - 1;
+        if (ds > TURN) {
+          DDBG(if (lane == 0) lk.dbg[11] -= clock64());
+          const int ps = ds & 1;
+          for (int i = lane + 1; i <= n - ds; i += WAVE) {
+            st_agent(xk + ds * XP + i, (int32_t)sm.accK[ps][i]);
+            st_agent(xi + ds * XP + i, (int32_t)sm.accI[ps][i]);
+            sm.accK[ps][i] = INF; sm.accI[ps][i] = INF;
+          }
+          drain_vmem();
+          if (lane == 0) st_agent(lk.flagB, base + ds);
+          DDBG(if (lane == 0) lk.dbg[11] += clock64());
+        }
+      } else if (D < n) {
+        // ---- workers: K items (32-cell blocks of split sweeps), then the far-shape items of the pairable cells
+        const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+        const int nK = (ncell + 31) >> 5, nE = e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);
+        const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
+        DDBG(if (lane == 0 && wave == 3) lk.dbg[12] -= clock64());
+        for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+          DDBG(if (lane == 0 && wave == 3) lk.dbg[14]++);
+          if (it < nK) mfe_k_item(sm, it, D, n, ncell, par, 0, lane, TURN + 1 + KEDGE, D - TURN - 2 - KEDGE);
+          else mfe_e_item<E_FAR>(sm, it - nK, D, par, pcnt, 0, lane, TermAU, e_bulge1, e_int23);
+        }
+        DDBG(if (lane == 0 && wave == 3) lk.dbg[12] += clock64());
+      }
+      DDBG(if (tid == 0) lk.dbg[13] -= clock64());
+      __syncthreads();
+      DDBG(if (tid == 0) lk.dbg[13] += clock64());
+      if (sm.fail) break;
+    }
+    if (sm.fail) break;
+  }
+  DDBG(if (tid == 0) lk.dbg[15] += clock64());
+}
+
+// grid = 2 R workgroups: 2r = main, 2r+1 = helper of sequence r.  LDS is one buffer used as either role's struct.
+template <int NT>
+__global__ __launch_bounds__(NT) void mfe_dual_kernel(MfeArgs A, DualLink lk) {
+  constexpr size_t BYTES = sizeof(MfeFastSmem<NT>) > sizeof(MfeHelperSmem<NT>) ? sizeof(MfeFastSmem<NT>) : sizeof(MfeHelperSmem<NT>);
+  __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
+  const int r = blockIdx.x >> 1;
+  // per-sequence slices of the link
+  lk.flagA += r * 64; lk.flagB += r * 64 + 32;
+  lk.xs += (long long)r * 256;
+  lk.xa = reinterpret_cast<int32_t*>(lk.xa) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
+  lk.xb = reinterpret_cast<int32_t*>(lk.xb) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
+  DDBG(lk.dbg += r * 64);
+  if (blockIdx.x & 1) mfe_helper<NT>(*reinterpret_cast<MfeHelperSmem<NT>*>(raw), A, r, lk);
+  else mfe_lds_body<NT, true>(*reinterpret_cast<MfeFastSmem<NT>*>(raw), A, r, lk);
+}
+
+}  // namespace drna

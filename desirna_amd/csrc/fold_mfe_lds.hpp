@@ -22,6 +22,7 @@
 namespace drna {
 
 constexpr int MFE_FAST_NMAX = 200;
+enum : int { E_ALL = 0, E_NEAR = 1, E_FAR = 2 };   // which shapes an E item / shape table covers (see mfe_e_item)
 constexpr int GSLOTS = 10;         // register-resident running minima per lane and parity (28 residues over >= 3 waves)
 
 template <int NT>
@@ -32,7 +33,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   static constexpr int NSLOT = 4 * WAVE;                                         // tower slots (n <= 256)
   static constexpr int NL = MFE_FAST_NMAX + 8;
   int fml[TRI + 8];
-  int wring[32 * RS];            // (c + TermAU(inner type)) * 256 + info   of the last 32 diagonals
+  int wring[33 * RS];            // (c + TermAU(inner type)) * 256 + info   of the last 32 diagonals; row 32 stays INF
   int ciring[32 * RS];           // c + mismatchI(inner side)               of the last 32 diagonals
   int dml[4 * RS];               // decomposition minima of the last 4 diagonals
   int hpl[MFE_FAST_NMAX + 2];    // hairpin size term by loop size
@@ -48,7 +49,10 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int xe[2][NL];                 // their 1x2 / 2x1 loop energies (two signed halves), inner TermAU taken out
   int pcnt[2];
   int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
-  int eshape[128];               // bulge / 1xn shape slots of the E items: s = u1+u2 | u1 << 8 | size term << 16
+  int eshape[128];               // bulge / 1xn shapes of the E items: s = u1+u2 | u1 << 8 | size term << 16 (static)
+  int sync_fail;                 // two-workgroup kernel: a wait for the helper expired
+  int etab[2][128];              // the same shapes as seen from one diagonal: byte offset of the inner pair's ring cell
+                                 // for column 0 | size term << 16 (shapes without an inner pair yet point at the INF row)
   int tw_L[32];                  // generic interior size term by total loop size s (INF below 6)
   int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
 };
@@ -69,6 +73,14 @@ struct FmlLds {
 // an unused part of its workspace (never read by the kernel).
 #ifndef DRNA_SKIP
 #define DRNA_SKIP 0          // diagnostic builds only: see fold_pf_lds.hpp
+#endif
+#ifdef DRNA_PROCLK
+#define PCLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long*>(A.ws + 2ll * A.ld * A.ld)[512 + (k)] = clock64(); } while (0)
+#else
+#define PCLK(k) do { } while (0)
+#endif
+#ifndef DRNA_FSKIP
+#define DRNA_FSKIP 0         // diagnostic builds only: parts of the cell finalize left out (1 stores, 2 hairpin, 4 fML, 8 side jobs, 16 all of it, 32 exterior stem)
 #endif
 #ifdef DRNA_STAMPS
 #define STAMP(k) do { long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
@@ -93,7 +105,7 @@ __device__ __forceinline__ void mfe_f5_column(MfeFastSmem<NT>& sm, const int32_t
 // no scalar instructions on offsets): residue rho of an inner diagonal -> ring offsets and size terms of
 // the tower entry that lives there on diagonal d.
 template <int NT>
-__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio) {
+__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio, int emode = E_ALL) {
   constexpr int RS = MfeFastSmem<NT>::RS;
   const int par = d & 1;
   if (tid >= 0 && tid < GRES) {
@@ -117,6 +129,7 @@ __device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, i
     int* e = sm.tower_tab[par][tid];
     e[0] = offA; e[1] = offB; e[2] = as; e[3] = fl; e[4] = L; e[5] = 0;
   }
+  if (tid >= 0 && tid < WAVE) mfe_prepare_etab(sm, d, tid, emode);
 }
 
 // one diagonal step of the register-resident generic-interior minima of a tower (branch-free, table-driven);
@@ -147,6 +160,201 @@ __device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G
   return acc;
 }
 
+// ---- work items shared by the one-workgroup kernel and by the two roles of the two-workgroup kernel (fold_mfe_dual.hpp)
+
+// K: multiloop splits of 32 cells x 4 interleaved split-point groups, tt = tt_lo .. tmax (all of them: TURN+1 .. d-TURN-2;
+// the helper of the two-workgroup kernel leaves KEDGE at either end to the main workgroup).  A lane owns two adjacent
+// cells (one ds_read2 per operand pair) and walks the compact triangle with running offsets: row tt starts
+// rowoff[tt+4] - rowoff[tt] = 4n - 4tt - 6 words after row tt-4... so offset += delta, delta -= 16 per step instead of a
+// table lookup per operand.  Minima go to accK by ds_min (order-free).
+template <class SM>
+__device__ __forceinline__ void mfe_k_item(SM& sm, int it, int d, int n, int ncell, int par, int slot0, int lane, int tt_lo, int tmax) {
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int g = lane >> 4, cl = lane & 15;
+  int i = (it << 5) + 2 * cl + 1;
+  const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+  i = act0 ? i : 1;
+  int tt = tt_lo + g;
+  const int rr = tt <= tmax ? d - tt - 1 : TURN + 1;
+  int offA = fml_off(tt, n) + i - 1, dA = 4 * n - 4 * tt - 6;            // fML[i, i+tt]
+  int offC = fml_off(rr, n) + i + tt, dC = -4 * n + 4 * rr - 6;          // fML[i+tt+1, j]
+  int m0 = INF, m1 = INF, m2 = INF, m3 = INF;                            // cell i: m0, m2; cell i+1: m1, m3
+  for (; tt + 12 <= tmax; tt += 16) {
+    const int oA1 = offA + dA, oA2 = oA1 + dA - 16, oA3 = oA2 + dA - 32;
+    const int oC1 = offC + dC, oC2 = oC1 + dC - 16, oC3 = oC2 + dC - 32;
+    const int a00 = sm.fml[offA], a01 = sm.fml[offA + 1], c00 = sm.fml[offC], c01 = sm.fml[offC + 1];
+    const int a10 = sm.fml[oA1], a11 = sm.fml[oA1 + 1], c10 = sm.fml[oC1], c11 = sm.fml[oC1 + 1];
+    const int a20 = sm.fml[oA2], a21 = sm.fml[oA2 + 1], c20 = sm.fml[oC2], c21 = sm.fml[oC2 + 1];
+    const int a30 = sm.fml[oA3], a31 = sm.fml[oA3 + 1], c30 = sm.fml[oC3], c31 = sm.fml[oC3 + 1];
+    offA = oA3 + dA - 48; offC = oC3 + dC - 48; dA -= 64; dC -= 64;
+    m0 = min(m0, min(a00 + c00, a20 + c20)); m1 = min(m1, min(a01 + c01, a21 + c21));
+    m2 = min(m2, min(a10 + c10, a30 + c30)); m3 = min(m3, min(a11 + c11, a31 + c31));
+  }
+  for (; tt <= tmax; tt += 4) {
+    m0 = min(m0, sm.fml[offA] + sm.fml[offC]);
+    m1 = min(m1, sm.fml[offA + 1] + sm.fml[offC + 1]);
+    offA += dA; offC += dC; dA -= 16; dC -= 16;
+  }
+  m0 = min(m0, m2); m1 = min(m1, m3);
+  if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
+  if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
+}
+
+// The 2 KEDGE split points next to either end of the range, tt = 4 .. 4+KEDGE-1 and d-4-KEDGE .. d-5: the ones that need the
+// KEDGE newest finished rows of fML, which the helper workgroup of the two-workgroup kernel does not have yet.  32 cells
+// per item, two adjacent cells per lane, the (at most 2 KEDGE) split points dealt to the four 16-lane groups.
+template <class SM>
+__device__ __forceinline__ void mfe_k_edge_item(SM& sm, int it, int d, int n, int ncell, int par, int slot0, int lane) {
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int g = lane >> 4, cl = lane & 15;
+  int i = (it << 5) + 2 * cl + 1;
+  const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+  i = act0 ? i : 1;
+  const int tmax = d - TURN - 2;
+  int m0 = INF, m1 = INF;
+#pragma unroll
+  for (int h = 0; h < (2 * KEDGE + 3) / 4; h++) {
+    const int e = g + 4 * h;                                       // 0 .. 2 KEDGE - 1
+    const int tt = e < KEDGE ? TURN + 1 + e : tmax - (2 * KEDGE - 1 - e);
+    const bool on = e < 2 * KEDGE && tt <= tmax && (e < KEDGE || tt >= TURN + 1 + KEDGE);
+    if (on) {
+      const int offA = fml_off(tt, n) + i - 1, offC = fml_off(d - tt - 1, n) + i + tt;
+      m0 = min(m0, sm.fml[offA] + sm.fml[offC]);
+      m1 = min(m1, sm.fml[offA + 1] + sm.fml[offC + 1]);
+    }
+  }
+  if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
+  if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
+}
+
+// E: 64 pairable cells per item (lane = compacted cell), one shape CLASS per item: bulges (0,u), bulges (u,0), loops (1,u),
+// loops (u,1) in parts of ESH shapes, or the fixed small shapes.  Everything about a shape is wave-uniform (ring row and
+// column offset of the inner pair, size term): lane k fetched the diagonal's table word of shape k once and the words are
+// broadcast with v_readlane, so a candidate costs one address add, one ring read, a shift, an add and a min -- instead
+// of a per-lane shape decode.  MODE: E_ALL = every shape (one-workgroup kernel); E_NEAR / E_FAR = the split of the
+// two-workgroup kernel: NEAR are the shapes whose inner pair sits at most four diagonals back ((0,0) (0,1) (1,0) (1,1)
+// (0,2) (2,0): one item per block), FAR everything else (its etab marks the two near bulges as padding).
+constexpr int ESH = 10, EPB = 13;   // one-workgroup kernel: shapes per E item; E items per block of 64 pairable cells (4 classes x 3 parts + small shapes)
+constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge class (u = 2 .. DLAG-3) and per 1xn class (u = 3 .. DLAG-4)
+template <int MODE>
+__device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 : EPB; }
+
+// candidates of NSH consecutive shapes of one class, starting at table entry `first` (entries that are padding in this
+// table read the INF row); bulges: ring word >> 8 + size term; 1xn loops: + the inner pair's 1xn mismatch
+template <int NSH, bool ONE_N, class SM>
+__device__ __forceinline__ int mfe_e_class(const SM& sm, const char* ring, int par, int first, int lane) {
+  const int tw = sm.etab[par][first + (lane & 31)];
+  int w[NSH], v = INF_DEV;
+#pragma unroll
+  for (int k = 0; k < NSH; k++) w[k] = *reinterpret_cast<const int*>(ring + (lane_table(tw, k) & 0xffff));
+  if (!ONE_N) {
+#pragma unroll
+    for (int k = 0; k < NSH; k++) v = min(v, (w[k] >> 8) + (lane_table(tw, k) >> 16));
+  } else {
+    int tb[NSH];
+#pragma unroll
+    for (int k = 0; k < NSH; k++) tb[k] = sm.xtab[SM::XT_MM1N + (w[k] & 127)];
+#pragma unroll
+    for (int k = 0; k < NSH; k++) v = min(v, (w[k] >> 8) + tb[k] + (lane_table(tw, k) >> 16));
+  }
+  return v;
+}
+
+// the nine fixed small shapes: (0,0) | (0,1) (1,0) | (1,1) | (1,2) (2,1) | (2,2) | (2,3) (3,2)
+template <class SM>
+__device__ __forceinline__ int mfe_e_small(const SM& sm, const char* ring, int d, int par, int qc, int pe, int ij, int e_bulge1,
+                                           int e_int23) {
+  constexpr int RS = SM::RS;
+  const int t8 = (ij >> 4) * 8;
+  auto cell = [&](int s_tot, int u1) -> int {          // ring word of the inner pair (uniform row, INF row if none)
+    const int dp = d - 2 - s_tot;
+    const int off = dp > TURN ? ((dp & 31) * RS + 1 + u1) * 4 : 32 * RS * 4;
+    return *reinterpret_cast<const int*>(ring + off);
+  };
+  const int xv = sm.xe[par][qc];
+  const int w00 = cell(0, 0), w01 = cell(1, 0), w10 = cell(1, 1), w11 = cell(2, 1), w12 = cell(3, 1), w21 = cell(3, 2),
+            w22 = cell(4, 2), w23 = cell(5, 2), w32 = cell(5, 3);
+  const int s00 = sm.xtab[SM::XT_STACK + t8 + ((w00 & 127) >> 4)], s01 = sm.xtab[SM::XT_STACK + t8 + ((w01 & 127) >> 4)],
+            s10 = sm.xtab[SM::XT_STACK + t8 + ((w10 & 127) >> 4)],
+            s11 = sm.xtab[SM::XT_INT11 + (t8 + ((w11 & 127) >> 4)) * 16 + (ij & 15)],
+            s23 = sm.xtab[SM::XT_MM23 + (w23 & 127)], s32 = sm.xtab[SM::XT_MM23 + (w32 & 127)];
+  int v = (w00 >> 8) + s00;
+  v = min(v, min((w01 >> 8) + s01, (w10 >> 8) + s10) + e_bulge1);
+  v = min(v, (w11 >> 8) + s11);
+  v = min(v, min((w12 >> 8) + ((xv << 16) >> 16), (w21 >> 8) + (xv >> 16)));
+  v = min(v, (w22 >> 8) + (pe >> 15));
+  v = min(v, min((w23 >> 8) + s23, (w32 >> 8) + s32) + e_int23 + sm.mm23[ij]);
+  return v;
+}
+
+// One E item.  E_ALL: item x of the block = part x % 3 (ESH shapes) of class x / 3, x = 12 the small shapes.  E_FAR (helper of
+// the two-workgroup kernel): item x = the whole class x, 29 / 27 table entries of which the near ones are padding.  E_NEAR
+// (main workgroup): item 0 = the near bulges of both classes, item 1 = the near 1xn loops of both classes and the small shapes.
+template <int MODE, class SM>
+__device__ __forceinline__ void mfe_e_item(SM& sm, int e, int d, int par, int pcnt, int slot0, int lane, int TermAU, int e_bulge1,
+                                           int e_int23) {
+  constexpr int IPB = e_items_per_block<MODE>();
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int blk = e / IPB, x = e - IPB * blk;
+  const int q = blk * WAVE + lane;
+  const int qc = q < pcnt ? q : pcnt - 1;
+  const int pe = sm.plist[par][qc];
+  const int i0 = pe & 255, ij = (pe >> 8) & 127;
+  const char* ring = reinterpret_cast<const char*>(sm.wring) + i0 * 4;
+  const int outer_b = (ij >> 4) > 2 ? TermAU : 0;
+  int v = INF;
+  if (MODE == E_ALL) {
+    const int cls = x / 3, part = x - 3 * cls;
+    if (cls < 2) v = mfe_e_class<ESH, false>(sm, ring, par, cls * 32 + part * ESH, lane) + outer_b;
+    else if (cls < 4) v = mfe_e_class<ESH, true>(sm, ring, par, cls * 32 + part * ESH, lane) + sm.mm1n[ij];
+    else v = mfe_e_small(sm, ring, d, par, qc, pe, ij, e_bulge1, e_int23);
+  } else if (MODE == E_FAR) {
+    if (x < 2) v = mfe_e_class<29, false>(sm, ring, par, x * 32, lane) + outer_b;
+    else v = mfe_e_class<27, true>(sm, ring, par, x * 32, lane) + sm.mm1n[ij];
+  } else {
+    if (x == 0) v = min(mfe_e_class<NEAR_B, false>(sm, ring, par, 0, lane), mfe_e_class<NEAR_B, false>(sm, ring, par, 32, lane)) + outer_b;
+    else v = min(min(mfe_e_class<NEAR_I, true>(sm, ring, par, 64, lane), mfe_e_class<NEAR_I, true>(sm, ring, par, 96, lane)) + sm.mm1n[ij],
+                 mfe_e_small(sm, ring, d, par, qc, pe, ij, e_bulge1, e_int23));
+  }
+  if (q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
+}
+
+// bulge / 1xn shapes as seen from diagonal d: where the inner pair of column 0 sits in the ring (bytes), and the size term;
+// mode E_NEAR / E_FAR keeps only the shapes of that side of the two-workgroup split
+template <class SM>
+__device__ __forceinline__ void mfe_prepare_etab(SM& sm, int d, int lane, int mode) {
+  constexpr int RS = SM::RS;
+  const int par = d & 1;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int x = lane + h * WAVE;
+    const int es = sm.eshape[x];
+    const int dp = d - 2 - (es & 255);
+    const bool near = (es & 255) <= DLAG - 3;                      // inner pair at most DLAG - 1 diagonals back
+    const bool live = dp > TURN && (es >> 16) != 0x3fff &&          // padding entries read the INF row too
+                      !(mode == E_FAR && near) && !(mode == E_NEAR && !near);
+    const int off = live ? ((dp & 31) * RS + 1 + ((es >> 8) & 255)) * 4 : 32 * RS * 4;
+    sm.etab[par][x] = off | (es & 0xffff0000);
+  }
+}
+
+// static shape table of the E items: shape x of class x >> 5: class 0 bulges (0,u) u = y+2 (y = x & 31 < 29), class 1 bulges
+// (u,0), class 2 1xn loops (1,u) u = y+3 (y < 27), class 3 (u,1); the rest is padding
+template <class SM>
+__device__ __forceinline__ void mfe_init_eshape(SM& sm, const MfeTables& T, int tid, int nthreads) {
+  for (int x = tid; x < 128; x += nthreads) {
+    const int c = x >> 5, y = x & 31;
+    int s_ = 2, u1_ = 0, L_ = 0x3fff;
+    if (c < 2 && y < 29) { s_ = y + 2; u1_ = c == 0 ? 0 : s_; L_ = T.bulge[s_]; }
+    if (c >= 2 && y < 27) {
+      const int u = y + 3;
+      s_ = u + 1; u1_ = c == 2 ? 1 : u;
+      L_ = T.interior[s_] + min(T.max_ninio, (u - 1) * T.ninio);
+    }
+    sm.eshape[x] = s_ | (u1_ << 8) | (L_ << 16);
+  }
+}
+
 // Structure of one diagonal step k (ONE workgroup barrier per diagonal):
 //   * waves 0..NB-1 ("finalize waves", one lane per tower slot) turn the minima gathered for diagonal
 //     k-1 into c / fML / ring rows, stream c to HBM, advance f5, and prepare the offset tables and the
@@ -162,9 +370,9 @@ __device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G
 //       K  multiloop splits tt = 4 + aw (mod NA) for all cells, lane = cell.
 // Uniform bookkeeping comes from LDS tables, not from scalar arithmetic: the scalar unit is shared by
 // the 16 waves and was the bottleneck of earlier versions of this kernel.
-template <int NT>
+template <int NT, bool DUAL = false>
 __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT,
-                             int32_t* __restrict__ PL) {
+                             int32_t* __restrict__ PL, int32_t* __restrict__ PLX, DualLink lk = DualLink{}) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = MfeFastSmem<NT>::RS;
   const MfeTables& T = *A.T;
@@ -188,39 +396,11 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
   for (int k = tid; k < 32 * RS; k += NT) { sm.wring[k] = INF * 256; sm.ciring[k] = INF; }   // idle tower entries read row 0
+  for (int k = tid; k < RS; k += NT) sm.wring[32 * RS + k] = INF * 256;
   for (int k = tid; k <= n; k += NT) { sm.hpl[k] = A.hp_len[k]; sm.rowoff[k] = k >= TURN + 1 ? fml_off(k, n) : 0; }
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
-  for (int x = tid; x < 128; x += NT) {
-    // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l:
-    // slots < 64 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3;
-    // y < 54: (u,1) u = y-24).  The spare slots carry the nine small shapes with tables of their own, told apart by a
-    // kind field: x = 58..60 the (1,2) (2,1) (2,2) loops (kinds 5..7: energy staged per cell), y = 54..59 stack (1),
-    // the two 1-bulges (2), 1x1 (3), (2,3) and (3,2) (4); what is left is padding with an unreachable size term
-    int s_, u1_, L_, kind_ = 0;
-    if (x < 64) {
-      const bool on = x < 58;
-      u1_ = (x < 29 || !on) ? 0 : x - 27;
-      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
-      L_ = on ? T.bulge[s_] : 0x3fff;
-      if (x >= 58 && x <= 60) { kind_ = x - 53; s_ = x == 60 ? 4 : 3; u1_ = x == 58 ? 1 : 2; L_ = 0; }
-    } else {
-      const int y = x - 64;
-      const bool on = y < 54;
-      u1_ = (y < 27 || !on) ? 1 : y - 24;
-      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
-      const int nl = s_ - 1;
-      L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
-      if (y >= 54 && y <= 59) {
-        const int z = y - 54;                 // (0,0) (0,1) (1,0) (1,1) (2,3) (3,2)
-        kind_ = z == 0 ? 1 : z <= 2 ? 2 : z == 3 ? 3 : 4;
-        s_ = z == 0 ? 0 : z <= 2 ? 1 : z == 3 ? 2 : 5;
-        u1_ = z <= 1 ? 0 : z <= 3 ? 1 : z - 2;
-        L_ = 0;
-      }
-    }
-    sm.eshape[x] = s_ | (kind_ << 5) | (u1_ << 8) | (L_ << 16);
-  }
+  mfe_init_eshape(sm, T, tid, NT);
   for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
   using SM = MfeFastSmem<NT>;
   for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
@@ -238,21 +418,45 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
       if (i <= n - d) t = pair_type(sm.Sp[i], sm.Sp[i + d]);
       const unsigned long long m = __ballot(t != 0);
       if (t) {
+        // list word i | pair info << 8 | e(2,2) << 15 and the staged (1,2) / (2,1) loop energies: these three small loops
+        // depend on the sequence alone, so their table energies (L2) are fetched here, once per fill, instead of on the
+        // per-diagonal critical path (inner TermAU taken out: it is folded into the ring word)
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        PL[d * ld + pos] = i | ((t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1]) << 8);
+        const int j = i + d, si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+        const bool va = d - 5 > TURN, vc = d - 6 > TURN;
+        const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
+                  tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
+        const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
+        const int s_ip2 = sm.S[i + 2], s_jm2 = sm.S[j - 2];
+        const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
+        const int eb = T.int21[tb ? (rb * 8 + t) * 64 + sj1 * 16 + si1 * 4 + s_ip2 : 0];
+        const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
+        const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
+                  cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
+        PL[d * ld + pos] = (i | ((t * 16 + si1 * 4 + sj1) << 8)) | (cc << 15);
+        PLX[d * ld + pos] = (a & 0xffff) | (b << 16);
       }
       base += __popcll(m);
     }
     if (lane == 0) PL[d * ld + ld - 1] = base;     // count kept in the last word of the row
   }
   __syncthreads();
+  PCLK(2);
+  if (DUAL) {
+    // round prologue for the helper workgroup: the pairing codes of this round (masked positions = 4), then the flag
+    int32_t* xs = lk.xs;
+    for (int k = tid; k <= n + 1; k += NT) st_agent(xs + k, (int32_t)sm.Sp[k]);
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0) { st_agent(lk.flagA, lk.base + TURN); sm.sync_fail = 0; }
+  }
   // tables and pairable list of the first diagonal
   if (aw < 0) {
     const int d = TURN + 1;
     if (d < n) {
-      mfe_prepare_tables<NT>(sm, d, tid, ninio, max_ninio);
+      mfe_prepare_tables<NT>(sm, d, tid, ninio, max_ninio, DUAL ? E_NEAR : E_ALL);
       const int cnt = PL[d * ld + ld - 1];
-      if (tid < cnt) { sm.plist[d & 1][tid] = PL[d * ld + tid]; sm.xe[d & 1][tid] = 0; }
+      if (tid < cnt) { sm.plist[d & 1][tid] = PL[d * ld + tid]; sm.xe[d & 1][tid] = PLX[d * ld + tid]; }
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
     }
   }
@@ -262,16 +466,62 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
 #endif
+  PCLK(3);
   if (aw < 0) {
     // ================= finalize waves
+    // two-workgroup kernel: the helper's results for diagonal d (split minima, far-shape minima) are fetched one step AHEAD
+    // into registers (pfK, pfI) whenever the flag read during the previous step shows them published, so that in the steady
+    // state -- helper a few diagonals ahead -- neither the flag nor the payload latency sits in the step
+    int32_t* const xw = reinterpret_cast<int32_t*>(lk.xa);
+    int32_t* const xf = xw + (MFE_FAST_NMAX + 2) * XP;
+    const int32_t* const xk = reinterpret_cast<const int32_t*>(lk.xb);
+    const int32_t* const xi = xk + (MFE_FAST_NMAX + 2) * XP;
+    int pfK = INF, pfI = INF, fbv = 0;
+    bool have = false;
+    if (DUAL) fbv = ld_agent(lk.flagB);
+    DDBG(if (tid == 0) lk.dbg[2] -= clock64());
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
+      // rows of diagonal d-2: stored in step k-2, complete since the end of step k-1 (see the counted wait before the barrier)
+      if (DUAL && tid == 0 && d - 2 > TURN) st_agent(lk.flagA, lk.base + d - 2);
+      // ---- top of the step: requests of the pipelined side jobs
+      // (the list row of diagonal k+1 and the exterior column's cells are requested here and consumed after the cell
+      // finalize, so that their L2 round trip overlaps it)
+      int pw[4] = {0, 0, 0, 0}, px[4] = {0, 0, 0, 0}, pw_cnt = 0, fx[4];
+      if (wave == w_pl && k + 1 < n) {
+        const int32_t* row = PL + (k + 1) * ld;
+        const int32_t* rowx = PLX + (k + 1) * ld;
+        pw_cnt = row[ld - 1];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
+      }
+      if (wave == w_q5 && k - 3 >= TURN + 2) {
+        const int j = k - 3;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int i = lane + 1 + c * WAVE;
+          fx[c] = i <= j - TURN - 1 ? EXT[j * ld + i] : INF;
+        }
+      }
       if (d > TURN) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
         const int dv = as_vector(d), dm1v = as_vector(d - 1);   // uniform LDS indices kept in VGPRs (outside divergent code)
-        if (i >= 1 && i <= ncell) {
-          const int aG = sm.accG[par][tid], aI = sm.accI[par][tid], aK = sm.accK[par][tid];
+        int bK = pfK, bI = pfI;
+        if (DUAL) {
+          if (!have) {                                           // not fetched ahead: wait for the helper here
+            DDBG(if (tid == 0) { lk.dbg[0]++; lk.dbg[1] -= clock64(); });
+            if (!sm.sync_fail && !wait_flag_wave(lk.flagB, lk.base + d)) sm.sync_fail = 1;
+            DDBG(if (tid == 0) lk.dbg[1] += clock64());
+            const bool on = i >= 1 && i <= ncell;
+            bK = on ? ld_agent(xk + d * XP + i) : INF;
+            bI = on ? ld_agent(xi + d * XP + i) : INF;
+          }
+        }
+        if (!(DRNA_FSKIP & 16) && i >= 1 && i <= ncell) {
+          const int aG = sm.accG[par][tid];
+          const int aI = DUAL ? min(sm.accI[par][tid], bI) : sm.accI[par][tid];
+          const int aK = DUAL ? min(sm.accK[par][tid], bK) : sm.accK[par][tid];
           sm.accG[par][tid] = INF; sm.accI[par][tid] = INF; sm.accK[par][tid] = INF;
           const int j = i + d;
           const int t = pair_type(sm.Sp[i], sm.Sp[j]);
@@ -279,7 +529,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           int c = INF, info = 0, cb = INF;
           if (t) {
             const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
-            c = mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
+            c = (DRNA_FSKIP & 2) ? 100 : mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
             c = min(c, aI);
             c = min(c, aG + sm.mmI[ij]);
             const int dml = sm.dml[((d - 2) & 3) * RS + i + 1];
@@ -291,10 +541,12 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           }
           sm.wring[(d & 31) * RS + i] = cb * 256 + info;
           sm.ciring[(d & 31) * RS + i] = c < INF ? c + sm.mmI[info] : INF;
-          Wc[d * ld + i] = c * 256 + info;
-          EXT[j * ld + i] = c < INF ? c + tau + mfe_extstem(sm, t, i, j, n) : INF;
+          if (!(DRNA_FSKIP & 1)) {
+            Wc[d * ld + i] = c * 256 + info;
+            EXT[j * ld + i] = c < INF ? c + tau + ((DRNA_FSKIP & 32) ? 0 : mfe_extstem(sm, t, i, j, n)) : INF;
+          }
           int f = INF;
-          if (d - 1 > TURN) {
+          if (!(DRNA_FSKIP & 4) && d - 1 > TURN) {
             const int ro1 = sm.rowoff[dm1v];
             const int fa = sm.fml[ro1 + i], fb = sm.fml[ro1 + i - 1];
             if (fa < HALF) f = fa + MLbase;
@@ -303,53 +555,71 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           if (c < INF) f = min(f, c + MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
           const int dec = aK >= HALF ? INF : aK;
           sm.dml[(d & 3) * RS + i] = dec;
-          sm.fml[sm.rowoff[dv] + i - 1] = min(f, dec);
+          const int fv = min(f, dec);
+          sm.fml[sm.rowoff[dv] + i - 1] = fv;
+          if (DUAL) {                                            // the helper's copies of the ring word and of fML
+#ifndef DRNA_DBG_NOST
+            st_agent(xw + d * XP + i, cb * 256 + info);
+            st_agent(xf + d * XP + i, fv);
+#endif
+          }
+        }
+        if (DUAL) {
+          // fetch ahead for diagonal d+1 if the flag value read one step ago covers it, and read the flag again for the next
+          // step.  Always exactly three loads, issued AFTER the step's stores, so that the counted wait before the barrier
+          // (stores_in_flight) leaves them in flight: they are consumed at the top of the next step
+          const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
+          have = d + 1 < n && flag_ge(__builtin_amdgcn_readfirstlane(fbv), lk.base + d + 1);
+          const bool on2 = have && i2 >= 1 && i2 <= ncell - 1;
+#ifndef DRNA_DBG_NOPF
+          pfK = ld_agent(on2 ? xk + (d + 1) * XP + i2 : lk.flagB);
+          pfI = ld_agent(on2 ? xi + (d + 1) * XP + i2 : lk.flagB);
+          if (!on2) { pfK = INF; pfI = INF; }
+#endif
+          fbv = ld_agent(lk.flagB);
         }
       }
       // side jobs of the step, one finalize wave each (when there are that many): tower table and pairable list of
       // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
-      // <= k-4, were stored in step <= k-3 and drained by the barrier that ended that step)
-      if (k + 1 < n) {
-        if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio);
+      // <= k-4, were stored in step <= k-3 and had landed by the end of step k-2)
+      if (!(DRNA_FSKIP & 8) && k + 1 < n) {
+        if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio, DUAL ? E_NEAR : E_ALL);
         if (wave == w_pl) {
-          // the (1,2) (2,1) (2,2) interior loops depend on the sequence alone: their table energies (L2) are fetched
-          // here, one diagonal ahead and off the sweep waves' critical path
           const int dn = k + 1;
-          const int32_t* row = PL + dn * ld;
-          const int cnt = row[ld - 1];
           int* dst = sm.plist[dn & 1];
           int* dxe = sm.xe[dn & 1];
-          int pe[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) pe[c] = row[min(lane + c * WAVE, ld - 1)];
-          const int nch = __builtin_amdgcn_readfirstlane((cnt + WAVE - 1) / WAVE);
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            if (c >= nch) break;                      // uniform: usually one or two chunks of 64 cells
-            const bool on = lane + c * WAVE < cnt;
-            const int i = on ? pe[c] & 255 : 1, cxv = (pe[c] >> 8) & 127, t = cxv >> 4, si1 = (cxv >> 2) & 3, sj1 = cxv & 3;
-            const int j = i + dn;
-            const bool va = on && dn - 5 > TURN, vc = on && dn - 6 > TURN;
-            const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
-                      tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
-            const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
-            const int s_ip2 = sm.S[i + 2], s_jm1 = sm.S[j - 1], s_jm2 = sm.S[j - 2];
-            const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
-            const int eb = T.int21[tb ? (rb * 8 + t) * 64 + s_jm1 * 16 + si1 * 4 + s_ip2 : 0];
-            const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
-            const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
-                      cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
-            if (lane + c * WAVE < MfeFastSmem<NT>::NL) {
-              dst[lane + c * WAVE] = (pe[c] & 0x7fff) | (cc << 15);
-              dxe[lane + c * WAVE] = (a & 0xffff) | (b << 16);
-            }
-          }
-          if (lane == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
+          for (int c = 0; c < 4; c++)
+            if (lane + c * WAVE < MfeFastSmem<NT>::NL) { dst[lane + c * WAVE] = pw[c]; dxe[lane + c * WAVE] = px[c]; }
+          if (lane == 0) { sm.pcnt[dn & 1] = pw_cnt; sm.qhead[dn & 1] = 0; }
         }
       }
-      if (wave == w_q5 && k - 3 >= TURN + 2) mfe_f5_column<NT>(sm, EXT, ld, k - 3, lane);
+      if (wave == w_q5 && k - 3 >= TURN + 2) {
+        const int j = k - 3;
+        int m = INF;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int i = lane + 1 + c * WAVE;
+          if (i <= j - TURN - 1 && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
+        }
+        m = wave_min_i32(m);
+        const int prev = sm.f5[j - 1];
+        sm.f5[j] = prev < m ? prev : m;
+      }
       STAMP(4);
-      __syncthreads();                     // one barrier per diagonal (drains vmcnt: c / EXT stores of this step)
+      DDBG(if (tid == 0) lk.dbg[3] -= clock64());
+      // every global load of the step has been consumed; what is still in flight are this step's stores (c, exterior term,
+      // and the two published words of the two-workgroup kernel): the wait lets exactly those stay in flight across the
+      // barrier, so the stores of the PREVIOUS step have landed -- which is what their readers rely on (exterior column
+      // three steps later, flagA two steps later) -- and no store latency sits in the step
+#ifdef DRNA_FIN_SYNC
+      __syncthreads();
+#else
+      stores_in_flight<DUAL ? 7 : 2>();
+      DDBG(if (tid == 0) { const long long t = clock64(); lk.dbg[3] += t; lk.dbg[4] -= t; });
+      lds_barrier();                       // one barrier per diagonal
+#endif
+      DDBG(if (tid == 0) lk.dbg[4] += clock64());
       STAMP(3);
     }
   } else {
@@ -358,6 +628,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 #pragma unroll
     for (int r = 0; r < GSLOTS; r++) { GE[r] = INF; GO[r] = INF; }
     const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
+    const int item_rank = NB < 3 ? aw : my_tb == 0 ? my_g : my_tb == NB - 1 ? NG + my_g : !pinned ? aw : 2 * NG + (aw - NG);
 
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
@@ -380,105 +651,24 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
         // pairable cells for the 112 bulge / 1xn shapes and the nine small fixed shapes (E).  Minima are order-free,
         // so who takes what does not matter.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5,      // two-workgroup kernel: the edge split points only
+                  nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<DUAL ? E_NEAR : E_ALL>() * ((pcnt + WAVE - 1) >> 6);
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
-        for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+        // one-workgroup kernel: items from the work queue (LDS counter).  Main role of the two-workgroup kernel: the few
+        // items left (edge split points, near shapes) are dealt statically, waves of the outer tower blocks -- whose towers
+        // die first -- before those of the centre blocks: no queue pops (a pop is an LDS atomic round trip of ~400 cycles)
+        int it = DUAL ? item_rank : queue_pop(&sm.qhead[par], lane);
+        for (; it < nItems; it = DUAL ? it + NA : queue_pop(&sm.qhead[par], lane)) {
           STAMP(6);
           if (it < nK) {
-            // ---- K: multiloop splits of 32 cells x 4 interleaved split-point groups.  A lane owns two adjacent cells
-            // (one ds_read2 per operand pair) and walks the compact triangle with running offsets: row tt starts
-            // rowoff[tt+4] - rowoff[tt] = 4n - 4tt - 6 words after row tt-4... so offset += delta, delta -= 16 per step
-            // instead of a table lookup per operand.
-            const int g = lane >> 4, cl = lane & 15;
-            int i = (it << 5) + 2 * cl + 1;
-            const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
-            i = act0 ? i : 1;
-            int tt = TURN + 1 + g;
-            const int tmax = d - TURN - 2;
-            const int rr = tt <= tmax ? d - tt - 1 : TURN + 1;
-            int offA = fml_off(tt, n) + i - 1, dA = 4 * n - 4 * tt - 6;            // fML[i, i+tt]
-            int offC = fml_off(rr, n) + i + tt, dC = -4 * n + 4 * rr - 6;          // fML[i+tt+1, j]
-            int m0 = INF, m1 = INF, m2 = INF, m3 = INF;                            // cell i: m0, m2; cell i+1: m1, m3
-            for (; tt + 12 <= tmax; tt += 16) {
-              const int oA1 = offA + dA, oA2 = oA1 + dA - 16, oA3 = oA2 + dA - 32;
-              const int oC1 = offC + dC, oC2 = oC1 + dC - 16, oC3 = oC2 + dC - 32;
-              const int a00 = sm.fml[offA], a01 = sm.fml[offA + 1], c00 = sm.fml[offC], c01 = sm.fml[offC + 1];
-              const int a10 = sm.fml[oA1], a11 = sm.fml[oA1 + 1], c10 = sm.fml[oC1], c11 = sm.fml[oC1 + 1];
-              const int a20 = sm.fml[oA2], a21 = sm.fml[oA2 + 1], c20 = sm.fml[oC2], c21 = sm.fml[oC2 + 1];
-              const int a30 = sm.fml[oA3], a31 = sm.fml[oA3 + 1], c30 = sm.fml[oC3], c31 = sm.fml[oC3 + 1];
-              offA = oA3 + dA - 48; offC = oC3 + dC - 48; dA -= 64; dC -= 64;
-              m0 = min(m0, min(a00 + c00, a20 + c20)); m1 = min(m1, min(a01 + c01, a21 + c21));
-              m2 = min(m2, min(a10 + c10, a30 + c30)); m3 = min(m3, min(a11 + c11, a31 + c31));
-            }
-            for (; tt <= tmax; tt += 4) {
-              m0 = min(m0, sm.fml[offA] + sm.fml[offC]);
-              m1 = min(m1, sm.fml[offA + 1] + sm.fml[offC + 1]);
-              offA += dA; offC += dC; dA -= 16; dC -= 16;
-            }
-            m0 = min(m0, m2); m1 = min(m1, m3);
-            if (act0 && m0 < HALF) atomicMin(&sm.accK[par][i + slot0], m0);
-            if (act1 && m1 < HALF) atomicMin(&sm.accK[par][i + 1 + slot0], m1);
+            if (DUAL) mfe_k_edge_item(sm, it, d, n, ncell, par, slot0, lane);
+            else mfe_k_item(sm, it, d, n, ncell, par, slot0, lane, TURN + 1, d - TURN - 2);
             STAMP(5);
 #ifdef DRNA_STAMPS
             st_acc[7]++;
 #endif
           } else {
-            // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in registers, the
-            // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.
-            // Slots 3 and 7 of some lanes are the nine small shapes (see the eshape table): same ring read, but the
-            // energy comes from the cell's staged values or from another table of xtab.
-            using SM = MfeFastSmem<NT>;
-            const int q = 4 * (it - nK) + (lane >> 4);
-            const int qc = q < pcnt ? q : pcnt - 1;
-            const int pe = sm.plist[par][qc], xv = sm.xe[par][qc];
-            const int i0 = pe & 255, ij = (pe >> 8) & 127;
-            int w[8], e_shape[8];
-            bool ok[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) e_shape[k] = sm.eshape[k * 16 + (lane & 15)];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-              const int dp = d - 2 - (e_shape[k] & 31);          // diagonal of the inner pair
-              ok[k] = dp > TURN;
-              w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 31) + i0];
-            }
-            const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij], outer_23 = sm.mm23[ij];
-            const int kind3 = (e_shape[3] >> 5) & 7, kind7 = (e_shape[7] >> 5) & 7;
-            const int f7 = w[7] & 127, tq = (ij >> 4) * 8 + (f7 >> 4);
-            int idx7 = SM::XT_MM1N + f7;
-            idx7 = kind7 == 4 ? SM::XT_MM23 + f7 : idx7;
-            idx7 = kind7 == 3 ? SM::XT_INT11 + tq * 16 + (ij & 15) : idx7;
-            idx7 = (kind7 == 1 || kind7 == 2) ? SM::XT_STACK + tq : idx7;
-            int tb[4];                                           // inner-side terms: one more LDS stage
-#pragma unroll
-            for (int k = 0; k < 3; k++) tb[k] = sm.xtab[SM::XT_MM1N + (w[k + 4] & 127)];
-            tb[3] = sm.xtab[idx7];
-            int add3 = (e_shape[3] >> 16) + outer_b;
-            add3 = kind3 == 5 ? (xv << 16) >> 16 : add3;
-            add3 = kind3 == 6 ? xv >> 16 : add3;
-            add3 = kind3 == 7 ? pe >> 15 : add3;
-            int add7 = (e_shape[7] >> 16) + outer_o;
-            add7 = (kind7 == 1 || kind7 == 3) ? 0 : add7;
-            add7 = kind7 == 2 ? e_bulge1 : add7;
-            add7 = kind7 == 4 ? e_int23 + outer_23 : add7;
-            int v = INF;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + outer_b;
-              v = min(v, ok[k] ? e : INF);
-            }
-            v = min(v, ok[3] ? (w[3] >> 8) + add3 : INF);
-#pragma unroll
-            for (int k = 4; k < 7; k++) {
-              const int e = (w[k] >> 8) + (e_shape[k] >> 16) + tb[k - 4] + outer_o;
-              v = min(v, ok[k] ? e : INF);
-            }
-            v = min(v, ok[7] ? (w[7] >> 8) + tb[3] + add7 : INF);
-            v = dpp_min_i32<0x111, 0xF>(v);
-            v = dpp_min_i32<0x112, 0xF>(v);
-            v = dpp_min_i32<0x114, 0xF>(v);
-            v = dpp_min_i32<0x118, 0xF>(v);
-            if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
+            mfe_e_item<DUAL ? E_NEAR : E_ALL>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
             STAMP(1);
 #ifdef DRNA_STAMPS
             st_acc[2]++;
@@ -497,6 +687,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
   }
 #endif
+  PCLK(4);
   // the remaining exterior columns (every store has landed: the loop ended with a draining barrier)
   if (wave == 0) {
     for (int j = max(TURN + 2, n - 2); j <= n; j++) mfe_f5_column<NT>(sm, EXT, ld, j, lane);
@@ -504,10 +695,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   __syncthreads();
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
-  __shared__ MfeFastSmem<NT> sm;
-  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+// one sequence, all pseudoknot rounds: prologue, fill, traceback.  DUAL: the main role of the two-workgroup kernel (lk links
+// it to its helper); every exit publishes DONE so that the helper leaves too
+template <int NT, bool DUAL>
+__device__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
   if (A.rg.len) A.L = A.rg.len[r];
   const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;      // offset in seqs / ss
   const int n = A.L, ld = A.ld, tid = threadIdx.x;
@@ -517,6 +708,8 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   int32_t* Wc = base;
   int32_t* EXT = base + 4 * tab;
   int32_t* PL = base + 3 * tab;      // compacted pairable-cell lists, one row per diagonal
+  int32_t* PLX = base + 1 * tab;     // their staged (1,2) / (2,1) loop energies
+  PCLK(0);
 
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
   for (int k = tid; k < 128; k += NT) {
@@ -525,7 +718,7 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   }
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
-  if (tid == 0) sm.flag = 0;
+  if (tid == 0) { sm.flag = 0; sm.sync_fail = 0; }
   __syncthreads();
   const char* seq = A.seqs + so;
   for (int k = tid; k < n; k += NT) {
@@ -542,7 +735,7 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
   }
   __syncthreads();
   if (sm.flag) {
-    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; }
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; if (DUAL) st_agent(lk.flagA, dual_done(lk.epoch)); }
     for (int k = tid; k < n; k += NT) A.ss[so + k] = '.';
     return;
   }
@@ -553,10 +746,14 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
 #ifdef DRNA_PHASECLK
     const long long pc0 = wall_clock64();
 #endif
-    mfe_fill_lds<NT>(sm, A, Wc, EXT, PL);           // ends with a barrier
+    lk.base = dual_base(lk.epoch, round);
+    PCLK(1);
+    mfe_fill_lds<NT, DUAL>(sm, A, Wc, EXT, PL, PLX, lk);           // ends with a barrier
+    PCLK(5);
 #ifdef DRNA_PHASECLK
     const long long pc1 = wall_clock64();
 #endif
+    if (DUAL && sm.sync_fail) { status = ST_SYNC; break; }
     if (wave_id() == 0) {
       const bool ok = (DRNA_SKIP & 256) ? true : mfe_traceback(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT);
 #ifdef DRNA_PHASECLK
@@ -569,6 +766,7 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
       }
     }
     __syncthreads();
+    PCLK(6);
     if (sm.flag) { status = ST_TRACEBACK; break; }
     const char op = round == 0 ? '(' : round == 1 ? '[' : round == 2 ? '<' : '{';
     const char cl = round == 0 ? ')' : round == 1 ? ']' : round == 2 ? '>' : '}';
@@ -588,8 +786,18 @@ __global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
     __syncthreads();
     if (!more) break;
   }
+  if (DUAL && tid == 0) st_agent(lk.flagA, dual_done(lk.epoch));
+  DDBG(if (tid == 0) lk.dbg[2] += clock64());
   for (int k = tid; k < n; k += NT) A.ss[so + k] = sm.sspk[k];
   if (tid == 0) A.status[r] = status;
+  PCLK(7);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void mfe_lds_kernel(MfeArgs A) {
+  __shared__ MfeFastSmem<NT> sm;
+  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+  mfe_lds_body<NT, false>(sm, A, r, DualLink{});
 }
 
 }  // namespace drna

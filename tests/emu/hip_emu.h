@@ -4,6 +4,8 @@
 // time: every GPU thread is an OS thread, __syncthreads() is a real barrier, wave collectives
 // (__shfl_xor, __ballot) rendezvous the 64 lanes of a wave.  Nothing here is part of the product.
 #pragma once
+#define DRNA_EMU 1
+#include <sched.h>
 #include <pthread.h>
 #include <stdint.h>
 

@@ -21,6 +21,19 @@ if has bench; then
   cat gpurun_out/bench.json
   echo "== bench design-like"; timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline > gpurun_out/bench_design.json 2>/dev/null || exit 1; cat gpurun_out/bench_design.json
 fi
+if has qbench; then
+  echo "== quick bench (no CPU baseline)"
+  timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > gpurun_out/qbench.json 2> gpurun_out/qbench.err || { tail -5 gpurun_out/qbench.err; exit 1; }
+  python3 -c "import json; d=json.load(open('gpurun_out/qbench.json')); print('QBENCH value %.0f  ms/step %.4f  kernel_ms %s' % (d['value'], d['ms_per_step'], d['kernel_ms']))"
+  timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline > gpurun_out/qbench_design.json 2>/dev/null || exit 1
+  python3 -c "import json; d=json.load(open('gpurun_out/qbench_design.json')); print('QBENCH design value %.0f  ms/step %.4f  kernel_ms %s' % (d['value'], d['ms_per_step'], d['kernel_ms']))"
+fi
+if has qsingle; then
+  echo "== quick bench, one workgroup per fold (DRNA_DUAL=0)"
+  DRNA_DUAL=0 timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > gpurun_out/qbench_single.json 2>/dev/null || exit 1
+  python3 -c "import json; d=json.load(open('gpurun_out/qbench_single.json')); print('QBENCH single value %.0f  ms/step %.4f  kernel_ms %s' % (d['value'], d['ms_per_step'], d['kernel_ms']))"
+fi
+if has qtests; then echo "== quick parity tests"; timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or config3 or edge or properties or L200 or config2 or maximum" > gpurun_out/pytest_q.log 2>&1; rc=$?; tail -3 gpurun_out/pytest_q.log; [ $rc -eq 0 ] || exit 1; fi
 if has prof; then
   echo "== rocprof kernel trace"
   rm -rf gpurun_out/prof; (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof" -o r2 -- python3 "$REPO/bench.py" --steps $STEPS --warmup 5 --no-cpu-baseline > "$REPO/gpurun_out/bench_prof.json" 2> "$REPO/gpurun_out/prof.err") || exit 1
