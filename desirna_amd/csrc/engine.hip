@@ -83,6 +83,7 @@ struct drna_engine {
   bool zero_copy = true;
   // two-workgroup kernels (small batches: 4 R <= CUs, n <= 200): exchange rows and flags, allocated on first use
   bool dual = true;               // DRNA_DUAL=0 turns them off
+  bool dual_force = false;        // option "dual" = 2: also beside a partition function (tests, diagnostics)
   int dual_cap = 0;               // sequences the exchange buffers hold
   int dual_epoch = 0;             // grows by one per launch; flags are never reset (fold_common.hpp, DualLink)
   int* d_dflags = nullptr;        // [2 kernels][dual_cap][64]
@@ -130,7 +131,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   e->cus = prop.multiProcessorCount;
-  if (const char* dv = getenv("DRNA_DUAL")) e->dual = atoi(dv) != 0;
+  if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
   HIP_TRY(upload(&e->d_plan, &e->H.plan, 1));
@@ -206,6 +207,13 @@ extern "C" void drna_destroy(drna_engine* e) {
   delete e;
 }
 
+extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
+  if (!e || !name) return DRNA_ERR_ARG;
+  if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
+  e->err = std::string("drna_set_option: unknown option ") + name;
+  return DRNA_ERR_ARG;
+}
+
 extern "C" const char* drna_last_error(const drna_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int drna_set_targets(drna_engine* e, int n_targets, int L, const char* targets) {
@@ -267,10 +275,14 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   HIP_TRY(hipSetDevice(e->device));
   const int ld = L + 2;
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
-  // small batches leave most CUs idle with one workgroup per fold (R = 64: 128 workgroups on 256 CUs): fold every sequence
-  // with a main and a helper workgroup instead (fold_mfe_dual.hpp).  Both folds of the call then fill the chip exactly, so
-  // this needs 4 R <= CUs; larger batches keep the one-workgroup kernels, which saturate the chip by themselves
-  const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4 * R <= e->cus;
+  // small batches leave most CUs idle with one workgroup per fold (R = 64: 128 workgroups on 256 CUs): the MFE fold then
+  // takes a main and a helper workgroup per sequence (fold_mfe_dual.hpp; the same split of the partition function did not
+  // pay).  Needs 4 R <= CUs; larger batches keep the one-workgroup kernels, which saturate the chip by themselves
+  // ... and it is worth it only where the MFE fold is the longer one: without the partition function (the MFE fold alone then
+  // takes 0.50 instead of 0.59 ms at R = 64 x L = 200) or with the pseudoknot re-folds (up to four fills).  Beside a partition
+  // function of the same batch (0.59 ms) it would only add load to the chip (the PF kernel runs 1 % slower at the lower clock)
+  const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4 * R <= e->cus &&
+                        (!want_pf || want_pk || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
       void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};

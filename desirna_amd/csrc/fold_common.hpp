@@ -26,7 +26,7 @@ struct Ragged {
   const int* off = nullptr;
 };
 
-// ---- two-workgroup kernels (fold_mfe_dual.hpp, fold_pf_dual.hpp): one sequence is folded by a MAIN workgroup (finalize,
+// ---- two-workgroup kernel (fold_mfe_dual.hpp): one sequence is folded by a MAIN workgroup (finalize,
 // towers, near shapes) and a HELPER workgroup on another CU (multiloop splits, far shapes) that runs a few diagonals
 // behind on rows the main one publishes.  Cross-CU visibility follows the CDNA4 guide: payload by agent-scope (sc1,
 // write-through / L1-bypassing) stores and loads, every storing wave drains vmcnt, workgroup barrier, then ONE lane stores
@@ -36,14 +36,14 @@ struct Ragged {
 // The helper works on diagonal D with rows <= D - DLAG only: multiloop split points further than KEDGE from either end of the
 // range, loop shapes whose inner pair is at least DLAG diagonals back.  The slack this buys (DLAG - 3 steps of the main
 // workgroup) has to cover the round trip through L2 / fabric (~3 us) plus the helper's own step.
-constexpr int DLAG = 8, KEDGE = DLAG - 5;
+constexpr int DLAG = 10, KEDGE = DLAG - 5;
 constexpr int XP = 224;           // row pitch of the exchange tables for n <= 200: rows are whole 128-byte lines
 struct DualLink {
   int* flagA = nullptr;           // written by the main workgroup: base + last published diagonal (base + 3 = round prologue done)
   int* flagB = nullptr;           // written by the helper: base + last diagonal whose results are published
   int32_t* xs = nullptr;          // main -> helper: pairing codes Sp[0 .. n+1] of the round (4 = masked)
-  void* xa = nullptr;             // main -> helper rows (MFE: wring word, fML; PF: see fold_pf_dual.hpp)
-  void* xb = nullptr;             // helper -> main rows (MFE: split minima, far-shape minima)
+  void* xa = nullptr;             // main -> helper rows (ring word, fML)
+  void* xb = nullptr;             // helper -> main rows (split minima, far-shape minima)
   long long* dbg = nullptr;       // diagnostic builds (-DDRNA_DUALDBG): cycle counters, 64 words per sequence
   int base = 0;                   // ((epoch * 8 + round) << 10)
   int epoch = 0;
@@ -69,6 +69,9 @@ __device__ __forceinline__ void stores_in_flight() {
 #ifndef DRNA_EMU
   if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }

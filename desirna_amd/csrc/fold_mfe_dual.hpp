@@ -34,7 +34,7 @@ struct MfeHelperSmem {
   int eshape[128], etab[2][128];
   int plist[2][NL], xe[2][1];       // xe: only named by the shared item code's small-shape branch, which the helper never takes
   int pcnt[2], qhead[2];
-  int flag, fail;
+  int flag, fail, failr[2];       // failr[D & 1]: set by the inbound wave during step D, read by everybody after the step's barrier
   unsigned char S[MFE_FAST_NMAX + 4], Sp[MFE_FAST_NMAX + 4];
 };
 
@@ -63,7 +63,7 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
   for (int k = tid; k < 33 * RS; k += NT) sm.wring[k] = INF * 256;
   for (int k = tid; k < SM::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accK[p][k] = INF; sm.accI[p][k] = INF; }
-  if (tid == 0) { sm.flag = 0; sm.fail = 0; }
+  if (tid == 0) { sm.flag = 0; sm.fail = 0; sm.failr[0] = 0; sm.failr[1] = 0; }
   __syncthreads();
   const char* seq = A.seqs + (long long)r * n;
   for (int k = tid; k < n; k += NT) {
@@ -102,6 +102,7 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
   };
 
   DDBG(if (tid == 0) lk.dbg[15] -= clock64());
+  bool failed = false;
   for (int round = 0; round <= A.pk_rounds; round++) {
     const int base = dual_base(lk.epoch, round);
     // ---- the round starts when the main workgroup has published its pairing codes (or ends the call)
@@ -116,15 +117,18 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
     if (wave == 0 && TURN + 1 < n) prepare(TURN + 1);
     __syncthreads();
 
-    for (int D = TURN + 1; D <= n; D++) {            // step D = n only ships the last diagonal
+    int fa = 0;
+    if (wave == 0) fa = ld_agent(lk.flagA);
+    for (int D = TURN + 1; D <= n + 1; D++) {        // steps D = n, n+1 only ship the last diagonal and raise its flag
       const int par = D & 1, ncell = n - D;
       if (wave == 0) {
-        // ---- inbound: rows of diagonal D+1-DLAG (needed from diagonal D+1 on)
+        // ---- inbound: rows of diagonal D+1-DLAG (needed from diagonal D+1 on); the flag was read at the end of the
+        // previous step, so the only latency in the step is one round of loads
         if (D + 1 < n) {
           const int dr = D + 1 - DLAG;
           if (dr > TURN) {
             DDBG(if (lane == 0) lk.dbg[8] -= clock64());
-            if (!sm.fail && !wait_flag_wave(lk.flagA, base + dr)) sm.fail = 1;
+            if (!flag_ge(__builtin_amdgcn_readfirstlane(fa), base + dr) && !wait_flag_wave(lk.flagA, base + dr)) sm.failr[D & 1] = 1;
             DDBG(if (lane == 0) { const long long t = clock64(); lk.dbg[8] += t; lk.dbg[9] -= t; });
             const int ro = fml_off(dr, n);
             int vw[4], vf[4];                                    // all eight loads in flight, then the LDS stores
@@ -143,14 +147,18 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
             DDBG(if (lane == 0) lk.dbg[9] += clock64());
           }
         }
+        fa = ld_agent(lk.flagA);                       // for the next step (left in flight across the barrier)
       } else if (wave == 2) {
         DDBG(if (lane == 0) lk.dbg[10] -= clock64());
         if (D + 1 < n) prepare(D + 1);               // tables of the next diagonal (sequence only: no wait)
         DDBG(if (lane == 0) lk.dbg[10] += clock64());
       } else if (wave == 1) {
-        // ---- outbound: minima of diagonal D-1 (reset for diagonal D+1), then the flag
+        // ---- outbound: the flag of diagonal D-2 (its minima were stored during the previous step: they have landed by
+        // now, so the wait is short), then the minima of diagonal D-1 (reset for diagonal D+1)
+        drain_vmem();
+        if (lane == 0 && D - 2 > TURN) st_agent(lk.flagB, base + D - 2);
         const int ds = D - 1;
-        if (ds > TURN) {
+        if (ds > TURN && ds < n) {
           DDBG(if (lane == 0) lk.dbg[11] -= clock64());
           const int ps = ds & 1;
           for (int i = lane + 1; i <= n - ds; i += WAVE) {
@@ -158,8 +166,6 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
             st_agent(xi + ds * XP + i, (int32_t)sm.accI[ps][i]);
             sm.accK[ps][i] = INF; sm.accI[ps][i] = INF;
           }
-          drain_vmem();
-          if (lane == 0) st_agent(lk.flagB, base + ds);
           DDBG(if (lane == 0) lk.dbg[11] += clock64());
         }
       } else if (D < n) {
@@ -178,9 +184,9 @@ __device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
       DDBG(if (tid == 0) lk.dbg[13] -= clock64());
       __syncthreads();
       DDBG(if (tid == 0) lk.dbg[13] += clock64());
-      if (sm.fail) break;
+      if (sm.failr[D & 1]) { failed = true; break; }         // (the other parity's word is the one step D+1 may write)
     }
-    if (sm.fail) break;
+    if (failed) break;
   }
   DDBG(if (tid == 0) lk.dbg[15] += clock64());
 }

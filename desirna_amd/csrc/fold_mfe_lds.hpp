@@ -482,8 +482,9 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     DDBG(if (tid == 0) lk.dbg[2] -= clock64());
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
-      // rows of diagonal d-2: stored in step k-2, complete since the end of step k-1 (see the counted wait before the barrier)
-      if (DUAL && tid == 0 && d - 2 > TURN) st_agent(lk.flagA, lk.base + d - 2);
+      // rows of diagonal d-1: stored in step k-1 and landed before its barrier (counted wait: in the two-workgroup kernel only
+      // the three fetch-ahead loads stay in flight)
+      if (DUAL && tid == 0 && d - 1 > TURN) st_agent(lk.flagA, lk.base + d - 1);
       // ---- top of the step: requests of the pipelined side jobs
       // (the list row of diagonal k+1 and the exterior column's cells are requested here and consumed after the cell
       // finalize, so that their L2 round trip overlaps it)
@@ -564,20 +565,6 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 #endif
           }
         }
-        if (DUAL) {
-          // fetch ahead for diagonal d+1 if the flag value read one step ago covers it, and read the flag again for the next
-          // step.  Always exactly three loads, issued AFTER the step's stores, so that the counted wait before the barrier
-          // (stores_in_flight) leaves them in flight: they are consumed at the top of the next step
-          const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
-          have = d + 1 < n && flag_ge(__builtin_amdgcn_readfirstlane(fbv), lk.base + d + 1);
-          const bool on2 = have && i2 >= 1 && i2 <= ncell - 1;
-#ifndef DRNA_DBG_NOPF
-          pfK = ld_agent(on2 ? xk + (d + 1) * XP + i2 : lk.flagB);
-          pfI = ld_agent(on2 ? xi + (d + 1) * XP + i2 : lk.flagB);
-          if (!on2) { pfK = INF; pfI = INF; }
-#endif
-          fbv = ld_agent(lk.flagB);
-        }
       }
       // side jobs of the step, one finalize wave each (when there are that many): tower table and pairable list of
       // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
@@ -615,7 +602,21 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 #ifdef DRNA_FIN_SYNC
       __syncthreads();
 #else
-      stores_in_flight<DUAL ? 7 : 2>();
+      if (DUAL && d > TURN) {
+        // fetch ahead for diagonal d+1 if the flag value read one step ago covers it, and read the flag again for the next
+        // step: always three loads, the last memory operations of the step, left in flight across the barrier
+        const int ncell = n - d;
+        const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
+        have = d + 1 < n && flag_ge(__builtin_amdgcn_readfirstlane(fbv), lk.base + d + 1);
+        const bool on2 = have && i2 >= 1 && i2 <= ncell - 1;
+#ifndef DRNA_DBG_NOPF
+        pfK = ld_agent(on2 ? xk + (d + 1) * XP + i2 : lk.flagB);
+        pfI = ld_agent(on2 ? xi + (d + 1) * XP + i2 : lk.flagB);
+        if (!on2) { pfK = INF; pfI = INF; }
+#endif
+        fbv = ld_agent(lk.flagB);
+      }
+      stores_in_flight<DUAL ? 3 : 2>();
       DDBG(if (tid == 0) { const long long t = clock64(); lk.dbg[3] += t; lk.dbg[4] -= t; });
       lds_barrier();                       // one barrier per diagonal
 #endif

@@ -162,6 +162,15 @@ int drna_ensemble_defect_batch_device(drna_engine *e, int R, int L, const char *
 /* device ms of the last drna_ensemble_defect_batch*: out[0] = inside kernel, out[1] = outside kernel */
 int drna_last_edef_timing(const drna_engine *e, float out[2]);
 
+/*
+ * Engine options.  "dual" (default 1): in batches small enough to leave half of the chip idle (4 R <= compute units, L <= 200)
+ * the MFE fold of every sequence is done by TWO workgroups (fold_mfe_dual.hpp) when it is the longer fold of the call (no
+ * partition function requested, or pseudoknot re-folds).  Results do not depend on it (integer minima: bit-identical).
+ * 0 = always one workgroup per sequence, 2 = two workgroups whenever the batch allows.  DRNA_DUAL in the environment sets
+ * the default.
+ */
+int drna_set_option(drna_engine *e, const char *name, int value);
+
 /* engine facts: out[0]=device, out[1]=max_R, out[2]=max_L, out[3]=threads per workgroup,
  * out[4]=compute units, out[5]=bytes of device workspace */
 int drna_info(const drna_engine *e, int64_t out[6]);

@@ -604,3 +604,35 @@ def test_pf_range_error_code():
             assert np.isfinite(ok["Epf"]).all()
         finally:
             eng.close()
+
+
+def test_two_workgroup_mfe_equals_one_workgroup(eng400, oracle, eterna_targets):
+    """Small batches fold the MFE with two workgroups per sequence (main + helper on another CU, fold_mfe_dual.hpp): same
+    energies, same structures (pk rounds included), bit for bit, as the one-workgroup kernel ("dual" off) and as the oracle;
+    lengths around the kernel's limits, a batch that does not fill the chip, repeated calls (the hand-shake flags are never
+    reset: they grow with every call)."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(2200)
+    for L, R, pk in ((200, 64, False), (200, 3, True), (137, 40, True), (64, 17, False), (23, 64, True), (12, 5, False)):
+        seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
+        eng400.set_targets(["." * L])
+        flags = E.NEED_MFE | E.NEED_PF | (E.NEED_PK if pk else 0)
+        eng400.set_option("dual", 2)                     # two workgroups even beside the partition function
+        try:
+            a = eng400.score_batch(seqs, flags)
+            b = eng400.score_batch(seqs, flags)
+            eng400.set_option("dual", 0)
+            c = eng400.score_batch(seqs, flags)
+        finally:
+            eng400.set_option("dual", 1)
+        d = eng400.score_batch(seqs, E.NEED_MFE | (E.NEED_PK if pk else 0))      # the default policy's two-workgroup case
+        assert d["mfe_ss"] == a["mfe_ss"] and (d["Emfe"] == a["Emfe"]).all()
+        assert a["mfe_ss"] == b["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == c["Emfe"]).all() and (a["Emfe"] == b["Emfe"]).all()
+        assert (a["Epf"].view(np.int64) == c["Epf"].view(np.int64)).all()
+        for k in (0, R - 1):
+            ss, e = oracle.mfe(seqs[k])
+            if pk:
+                ss = oracle.pk_struct(seqs[k], ss)
+            assert a["mfe_ss"][k] == ss and int(a["Emfe"][k]) == e
+    with pytest.raises(E.EngineError):
+        eng400.set_option("no-such-option", 1)
