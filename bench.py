@@ -252,12 +252,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    eng.timing_sums(reset=True)                     # the engine sums its HIP-event kernel times over the timed calls itself
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, k == args.steps - 1)
-        t = eng.last_timing()
-        for key in tk:
-            tk[key] += t[key]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,8 +264,9 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    ts = eng.timing_sums()
     for key in tk:
-        tk[key] /= max(1, args.steps)
+        tk[key] = ts[key] / max(1, ts["calls"])
 
     if rank == 0:
         folds = R * world * args.steps

@@ -58,6 +58,7 @@ struct drna_engine {
   hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_m0 = nullptr, ev_m1 = nullptr, ev_p0 = nullptr,
              ev_p1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
   float timing[4] = {0, 0, 0, 0};
+  double timing_sum[5] = {0, 0, 0, 0, 0};     // mfe, pf, eval, total ms summed over drna_score_batch_device calls; [4] = calls
   // ensemble defect (outside recursion): workspace allocated on first use
   double* d_ws_out = nullptr;
   double* d_edef = nullptr;
@@ -278,11 +279,11 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // small batches leave most CUs idle with one workgroup per fold (R = 64: 128 workgroups on 256 CUs): the MFE fold then
   // takes a main and a helper workgroup per sequence (fold_mfe_dual.hpp; the same split of the partition function did not
   // pay).  Needs 4 R <= CUs; larger batches keep the one-workgroup kernels, which saturate the chip by themselves
-  // ... and it is worth it only where the MFE fold is the longer one: without the partition function (the MFE fold alone then
-  // takes 0.50 instead of 0.59 ms at R = 64 x L = 200) or with the pseudoknot re-folds (up to four fills).  Beside a partition
-  // function of the same batch (0.59 ms) it would only add load to the chip (the PF kernel runs 1 % slower at the lower clock)
+  // (R = 64 x L = 200: the MFE fold takes 0.50 instead of 0.59 ms, 1.65 instead of 1.81 ms with the pseudoknot re-folds; the
+  // partition function running beside it loses 1 % to the busier chip's lower clock)
+  // Shorter sequences do not repay the hand-shake (measured break-even at n = 160: tools/dual_lengths.py).
   const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4 * R <= e->cus &&
-                        (!want_pf || want_pk || e->dual_force);
+                        (L >= 170 || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
       void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
@@ -345,21 +346,28 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     return DRNA_OK;
   };
   const bool mfe_first = want_mfe && (!want_pf || e->timing[0] > e->timing[1]);
-  if (mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
-  if (want_pf) { const int rc = enqueue_pf(); if (rc != DRNA_OK) return rc; }
-  if (want_mfe && !mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
-  if (want_ev) {
+  // the evaluation kernel (~20 us) rides in FRONT of the shorter fold on that fold's stream: one stream less to drain at the end
+  hipStream_t s_ev = e->s_eval;
+  if (want_ev && want_mfe && want_pf) s_ev = mfe_first ? e->s_pf : e->s_mfe;
+  auto enqueue_eval = [&]() -> int {
     EvalArgs a;
     a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
     a.seqs = d_seqs; a.pt = e->d_pt; a.L = L; a.n_targets = e->n_targets; a.Ed = d_Ed;
-    HIP_TRY(hipEventRecord(e->ev_e0, e->s_eval));
-    hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, e->s_eval, a);
+    HIP_TRY(hipEventRecord(e->ev_e0, s_ev));
+    hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, s_ev, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev_e1, e->s_eval));
-  }
-  // join on the host: the three streams are drained one after the other (a device-side join -- stream-wait-event packets
+    HIP_TRY(hipEventRecord(e->ev_e1, s_ev));
+    return DRNA_OK;
+  };
+  if (mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
+  if (want_ev && s_ev == e->s_pf) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
+  if (want_pf) { const int rc = enqueue_pf(); if (rc != DRNA_OK) return rc; }
+  if (want_ev && s_ev == e->s_mfe) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
+  if (want_mfe && !mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
+  if (want_ev && s_ev == e->s_eval) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
+  // join on the host: the streams are drained one after the other (a device-side join -- stream-wait-event packets
   // plus an end marker -- costs ~15 us after the last kernel); "total" = first start event to the latest end event
-  if (want_ev) HIP_TRY(hipStreamSynchronize(e->s_eval));
+  if (want_ev && s_ev == e->s_eval) HIP_TRY(hipStreamSynchronize(e->s_eval));
   if (mfe_first && want_pf) HIP_TRY(hipStreamSynchronize(e->s_pf));
   if (want_mfe) HIP_TRY(hipStreamSynchronize(e->s_mfe));
   if (!mfe_first && want_pf) HIP_TRY(hipStreamSynchronize(e->s_pf));
@@ -374,6 +382,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     if (want_pf) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_p1)); tot = t > tot ? t : tot; }
     if (want_ev) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_e1)); tot = t > tot ? t : tot; }
     e->timing[3] = tot;
+    for (int k = 0; k < 4; k++) e->timing_sum[k] += e->timing[k];
+    e->timing_sum[4] += 1.0;
   }
   for (int r = 0; r < R; r++) {
     const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
@@ -390,7 +400,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       e->err = buf;
       return DRNA_ERR_PF_RANGE;
     }
-    snprintf(buf, sizeof buf, "sequence %d: traceback could not reproduce a table value", r);
+    if (st == ST_SYNC) snprintf(buf, sizeof buf, "sequence %d: the two workgroups of the fold lost each other (a wait expired)", r);
+    else snprintf(buf, sizeof buf, "sequence %d: traceback could not reproduce a table value", r);
     e->err = buf;
     return DRNA_ERR_INTERNAL;
   }
@@ -444,6 +455,13 @@ extern "C" int drna_score_batch(drna_engine* e, int R, int L, const char* seqs, 
 extern "C" int drna_last_timing(const drna_engine* e, float out[4]) {
   if (!e || !out) return DRNA_ERR_ARG;
   for (int k = 0; k < 4; k++) out[k] = e->timing[k];
+  return DRNA_OK;
+}
+
+extern "C" int drna_timing_sums(drna_engine* e, double out[5], int reset) {
+  if (!e) return DRNA_ERR_ARG;
+  if (out) for (int k = 0; k < 5; k++) out[k] = e->timing_sum[k];
+  if (reset) for (int k = 0; k < 5; k++) e->timing_sum[k] = 0.0;
   return DRNA_OK;
 }
 

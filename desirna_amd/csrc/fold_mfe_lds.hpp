@@ -22,7 +22,7 @@
 namespace drna {
 
 constexpr int MFE_FAST_NMAX = 200;
-enum : int { E_ALL = 0, E_NEAR = 1, E_FAR = 2 };   // which shapes an E item / shape table covers (see mfe_e_item)
+enum : int { E_ALL = 0, E_NEAR = 1, E_FAR = 2, E_COARSE = 3 };   // which shapes an E item / shape table covers (see mfe_e_item)
 constexpr int GSLOTS = 10;         // register-resident running minima per lane and parity (28 residues over >= 3 waves)
 
 template <int NT>
@@ -49,7 +49,8 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int xe[2][NL];                 // their 1x2 / 2x1 loop energies (two signed halves), inner TermAU taken out
   int pcnt[2];
   int qhead[2];                  // work-queue head of the diagonal's floating items (K sub-blocks, E cell pairs, X groups)
-  int eshape[128];               // bulge / 1xn shapes of the E items: s = u1+u2 | u1 << 8 | size term << 16 (static)
+  int eshape[128];               // bulge / 1xn shapes of the shape-uniform E items: s = u1+u2 | u1 << 8 | size term << 16 (static)
+  int eshape_rows[128];          // shape slots of the 16-lane-row E items (one-workgroup kernel): s | kind << 5 | u1 << 8 | size term << 16
   int sync_fail;                 // two-workgroup kernel: a wait for the helper expired
   int etab[2][128];              // the same shapes as seen from one diagonal: byte offset of the inner pair's ring cell
                                  // for column 0 | size term << 16 (shapes without an inner pair yet point at the INF row)
@@ -234,10 +235,14 @@ __device__ __forceinline__ void mfe_k_edge_item(SM& sm, int it, int d, int n, in
 // of a per-lane shape decode.  MODE: E_ALL = every shape (one-workgroup kernel); E_NEAR / E_FAR = the split of the
 // two-workgroup kernel: NEAR are the shapes whose inner pair sits at most four diagonals back ((0,0) (0,1) (1,0) (1,1)
 // (0,2) (2,0): one item per block), FAR everything else (its etab marks the two near bulges as padding).
+#ifndef DRNA_ECOARSE
+#define DRNA_ECOARSE 32
+#endif
+constexpr int ECOARSE = DRNA_ECOARSE;   // at most this many pairable cells on the diagonal: coarse E items
 constexpr int ESH = 10, EPB = 13;   // one-workgroup kernel: shapes per E item; E items per block of 64 pairable cells (4 classes x 3 parts + small shapes)
 constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge class (u = 2 .. DLAG-3) and per 1xn class (u = 3 .. DLAG-4)
 template <int MODE>
-__device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 : EPB; }
+__device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 : MODE == E_COARSE ? 5 : EPB; }
 
 // candidates of NSH consecutive shapes of one class, starting at table entry `first` (entries that are padding in this
 // table read the INF row); bulges: ring word >> 8 + size term; 1xn loops: + the inner pair's 1xn mismatch
@@ -308,6 +313,16 @@ __device__ __forceinline__ void mfe_e_item(SM& sm, int e, int d, int par, int pc
     if (cls < 2) v = mfe_e_class<ESH, false>(sm, ring, par, cls * 32 + part * ESH, lane) + outer_b;
     else if (cls < 4) v = mfe_e_class<ESH, true>(sm, ring, par, cls * 32 + part * ESH, lane) + sm.mm1n[ij];
     else v = mfe_e_small(sm, ring, d, par, qc, pe, ij, e_bulge1, e_int23);
+  } else if (MODE == E_COARSE) {
+    // few pairable cells (short sequences, late diagonals): one item per class, its three parts one after the other, so that
+    // the per-item costs (queue pop, list and table reads) are paid 5 instead of 13 times
+    if (x < 4) {
+      const int first = x * 32;
+      if (x < 2) v = min(min(mfe_e_class<ESH, false>(sm, ring, par, first, lane), mfe_e_class<ESH, false>(sm, ring, par, first + ESH, lane)),
+                         mfe_e_class<ESH, false>(sm, ring, par, first + 2 * ESH, lane)) + outer_b;
+      else v = min(min(mfe_e_class<ESH, true>(sm, ring, par, first, lane), mfe_e_class<ESH, true>(sm, ring, par, first + ESH, lane)),
+                   mfe_e_class<ESH, true>(sm, ring, par, first + 2 * ESH, lane)) + sm.mm1n[ij];
+    } else v = mfe_e_small(sm, ring, d, par, qc, pe, ij, e_bulge1, e_int23);
   } else if (MODE == E_FAR) {
     if (x < 2) v = mfe_e_class<29, false>(sm, ring, par, x * 32, lane) + outer_b;
     else v = mfe_e_class<27, true>(sm, ring, par, x * 32, lane) + sm.mm1n[ij];
@@ -353,6 +368,76 @@ __device__ __forceinline__ void mfe_init_eshape(SM& sm, const MfeTables& T, int 
     }
     sm.eshape[x] = s_ | (u1_ << 8) | (L_ << 16);
   }
+}
+
+// E item of the one-workgroup kernel: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in
+// registers, the row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.  Slots
+// 3 and 7 of some lanes are the nine small shapes (see eshape_rows): same ring read, but the energy comes from the cell's
+// staged values or from another table of xtab.  (The shape-uniform items of mfe_e_item need a third of the instructions but
+// more items per diagonal; with sixteen waves sharing one work queue this form is faster up to n = 200: 0.245 vs 0.281 ms at
+// n = 100, equal at 200.)
+template <int NT>
+__device__ __forceinline__ void mfe_e_item_rows(MfeFastSmem<NT>& sm, int e, int d, int par, int pcnt, int slot0, int lane, int TermAU,
+                                                int e_bulge1, int e_int23) {
+  constexpr int RS = MfeFastSmem<NT>::RS;
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int it = e, nK = 0;
+  // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in registers, the
+  // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.
+  // Slots 3 and 7 of some lanes are the nine small shapes (see the eshape table): same ring read, but the
+  // energy comes from the cell's staged values or from another table of xtab.
+  using SM = MfeFastSmem<NT>;
+  const int q = 4 * (it - nK) + (lane >> 4);
+  const int qc = q < pcnt ? q : pcnt - 1;
+  const int pe = sm.plist[par][qc], xv = sm.xe[par][qc];
+  const int i0 = pe & 255, ij = (pe >> 8) & 127;
+  int w[8], e_shape[8];
+  bool ok[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) e_shape[k] = sm.eshape_rows[k * 16 + (lane & 15)];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int dp = d - 2 - (e_shape[k] & 31);          // diagonal of the inner pair
+    ok[k] = dp > TURN;
+    w[k] = sm.wring[(dp & 31) * RS + 1 + ((e_shape[k] >> 8) & 31) + i0];
+  }
+  const int outer_b = (ij >> 4) > 2 ? TermAU : 0, outer_o = sm.mm1n[ij], outer_23 = sm.mm23[ij];
+  const int kind3 = (e_shape[3] >> 5) & 7, kind7 = (e_shape[7] >> 5) & 7;
+  const int f7 = w[7] & 127, tq = (ij >> 4) * 8 + (f7 >> 4);
+  int idx7 = SM::XT_MM1N + f7;
+  idx7 = kind7 == 4 ? SM::XT_MM23 + f7 : idx7;
+  idx7 = kind7 == 3 ? SM::XT_INT11 + tq * 16 + (ij & 15) : idx7;
+  idx7 = (kind7 == 1 || kind7 == 2) ? SM::XT_STACK + tq : idx7;
+  int tb[4];                                           // inner-side terms: one more LDS stage
+#pragma unroll
+  for (int k = 0; k < 3; k++) tb[k] = sm.xtab[SM::XT_MM1N + (w[k + 4] & 127)];
+  tb[3] = sm.xtab[idx7];
+  int add3 = (e_shape[3] >> 16) + outer_b;
+  add3 = kind3 == 5 ? (xv << 16) >> 16 : add3;
+  add3 = kind3 == 6 ? xv >> 16 : add3;
+  add3 = kind3 == 7 ? pe >> 15 : add3;
+  int add7 = (e_shape[7] >> 16) + outer_o;
+  add7 = (kind7 == 1 || kind7 == 3) ? 0 : add7;
+  add7 = kind7 == 2 ? e_bulge1 : add7;
+  add7 = kind7 == 4 ? e_int23 + outer_23 : add7;
+  int v = INF;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int e = (w[k] >> 8) + (e_shape[k] >> 16) + outer_b;
+    v = min(v, ok[k] ? e : INF);
+  }
+  v = min(v, ok[3] ? (w[3] >> 8) + add3 : INF);
+#pragma unroll
+  for (int k = 4; k < 7; k++) {
+    const int e = (w[k] >> 8) + (e_shape[k] >> 16) + tb[k - 4] + outer_o;
+    v = min(v, ok[k] ? e : INF);
+  }
+  v = min(v, ok[7] ? (w[7] >> 8) + tb[3] + add7 : INF);
+  v = dpp_min_i32<0x111, 0xF>(v);
+  v = dpp_min_i32<0x112, 0xF>(v);
+  v = dpp_min_i32<0x114, 0xF>(v);
+  v = dpp_min_i32<0x118, 0xF>(v);
+  if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
 }
 
 // Structure of one diagonal step k (ONE workgroup barrier per diagonal):
@@ -401,6 +486,36 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   for (int k = tid; k < MfeFastSmem<NT>::NSLOT; k += NT)
     for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
   mfe_init_eshape(sm, T, tid, NT);
+  for (int x = tid; x < 128; x += NT) {
+    // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l:
+    // slots < 64 bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3;
+    // y < 54: (u,1) u = y-24).  The spare slots carry the nine small shapes with tables of their own, told apart by a
+    // kind field: x = 58..60 the (1,2) (2,1) (2,2) loops (kinds 5..7: energy staged per cell), y = 54..59 stack (1),
+    // the two 1-bulges (2), 1x1 (3), (2,3) and (3,2) (4); what is left is padding with an unreachable size term
+    int s_, u1_, L_, kind_ = 0;
+    if (x < 64) {
+      const bool on = x < 58;
+      u1_ = (x < 29 || !on) ? 0 : x - 27;
+      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
+      L_ = on ? T.bulge[s_] : 0x3fff;
+      if (x >= 58 && x <= 60) { kind_ = x - 53; s_ = x == 60 ? 4 : 3; u1_ = x == 58 ? 1 : 2; L_ = 0; }
+    } else {
+      const int y = x - 64;
+      const bool on = y < 54;
+      u1_ = (y < 27 || !on) ? 1 : y - 24;
+      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
+      const int nl = s_ - 1;
+      L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
+      if (y >= 54 && y <= 59) {
+        const int z = y - 54;                 // (0,0) (0,1) (1,0) (1,1) (2,3) (3,2)
+        kind_ = z == 0 ? 1 : z <= 2 ? 2 : z == 3 ? 3 : 4;
+        s_ = z == 0 ? 0 : z <= 2 ? 1 : z == 3 ? 2 : 5;
+        u1_ = z <= 1 ? 0 : z <= 3 ? 1 : z - 2;
+        L_ = 0;
+      }
+    }
+    sm.eshape_rows[x] = s_ | (kind_ << 5) | (u1_ << 8) | (L_ << 16);
+  }
   for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
   using SM = MfeFastSmem<NT>;
   for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
@@ -653,7 +768,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         // pairable cells for the 112 bulge / 1xn shapes and the nine small fixed shapes (E).  Minima are order-free,
         // so who takes what does not matter.
         const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5,      // two-workgroup kernel: the edge split points only
-                  nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<DUAL ? E_NEAR : E_ALL>() * ((pcnt + WAVE - 1) >> 6);
+                  nE = (DRNA_SKIP & 2) ? 0 : DUAL ? 2 * ((pcnt + WAVE - 1) >> 6) : (pcnt + 3) >> 2;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
         // one-workgroup kernel: items from the work queue (LDS counter).  Main role of the two-workgroup kernel: the few
         // items left (edge split points, near shapes) are dealt statically, waves of the outer tower blocks -- whose towers
@@ -669,7 +784,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
             st_acc[7]++;
 #endif
           } else {
-            mfe_e_item<DUAL ? E_NEAR : E_ALL>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
+            if (DUAL) mfe_e_item<E_NEAR>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
+            else mfe_e_item_rows<NT>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
             STAMP(1);
 #ifdef DRNA_STAMPS
             st_acc[2]++;

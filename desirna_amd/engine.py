@@ -25,7 +25,7 @@ EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
            "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
-           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option")
+           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums")
 
 RNG_WORDS = 625        # DRNA_RNG_WORDS: uint32 words of one replica's MT19937 stream
 
@@ -61,6 +61,8 @@ def load_library(path=None):
     L.drna_last_timing.argtypes = [vp, vp]
     L.drna_info.restype = ci
     L.drna_info.argtypes = [vp, vp]
+    L.drna_timing_sums.restype = ci
+    L.drna_timing_sums.argtypes = [vp, vp, ci]
     L.drna_set_option.restype = ci
     L.drna_set_option.argtypes = [vp, C.c_char_p, ci]
     L.drna_ensemble_defect_batch.restype = ci
@@ -318,6 +320,12 @@ class Engine:
         out = (C.c_float * 4)()
         self._check(self._L.drna_last_timing(self._h, out))
         return {"mfe": out[0], "pf": out[1], "eval": out[2], "total": out[3]}
+
+    def timing_sums(self, reset=False):
+        """device ms summed over the score_batch[_device] calls since the last reset: dict(mfe, pf, eval, total, calls)"""
+        out = (C.c_double * 5)()
+        self._check(self._L.drna_timing_sums(self._h, out, int(bool(reset))))
+        return {"mfe": out[0], "pf": out[1], "eval": out[2], "total": out[3], "calls": int(out[4])}
 
     def info(self):
         out = (C.c_int64 * 6)()

@@ -159,15 +159,18 @@ int drna_ensemble_defect_batch(drna_engine *e, int R, int L, const char *seqs, d
 int drna_ensemble_defect_batch_device(drna_engine *e, int R, int L, const char *d_seqs, double *d_edef,
                                       double *d_bpp);
 
+/* device ms summed over the drna_score_batch[_device] calls since the last reset: out[0..3] as drna_last_timing, out[4] = number
+ * of calls; out may be NULL (reset only).  Lets a caller time a loop of calls without a query per call. */
+int drna_timing_sums(drna_engine *e, double out[5], int reset);
+
 /* device ms of the last drna_ensemble_defect_batch*: out[0] = inside kernel, out[1] = outside kernel */
 int drna_last_edef_timing(const drna_engine *e, float out[2]);
 
 /*
  * Engine options.  "dual" (default 1): in batches small enough to leave half of the chip idle (4 R <= compute units, L <= 200)
- * the MFE fold of every sequence is done by TWO workgroups (fold_mfe_dual.hpp) when it is the longer fold of the call (no
- * partition function requested, or pseudoknot re-folds).  Results do not depend on it (integer minima: bit-identical).
- * 0 = always one workgroup per sequence, 2 = two workgroups whenever the batch allows.  DRNA_DUAL in the environment sets
- * the default.
+ * the MFE fold of every sequence of at least 170 nt is done by TWO workgroups (fold_mfe_dual.hpp).  Results do not depend
+ * on it (integer minima: bit-identical).  0 = always one workgroup per sequence, 2 = two workgroups whenever the batch allows,
+ * whatever the length.  DRNA_DUAL in the environment sets the default.
  */
 int drna_set_option(drna_engine *e, const char *name, int value);
 
