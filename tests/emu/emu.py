@@ -20,6 +20,7 @@ def build():
     vp, ci = C.c_void_p, C.c_int
     L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
+    L.emu_mfe_dual.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, vp, vp, vp]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
@@ -49,6 +50,17 @@ class Emu:
         assert rc == 0
         out = (E, [bytes(r).decode() for r in ss], st)
         return out + (Wc, F) if dump else out
+
+    def mfe_dual(self, seqs, pk_rounds=0, nt=256, calls=1):
+        """two-workgroup MFE kernel (main + helper side by side); returns (Emfe, structures, status)"""
+        R, L = len(seqs), len(seqs[0])
+        E = np.zeros(R, dtype=np.int32)
+        ss = np.zeros((R, L), dtype=np.uint8)
+        st = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_mfe_dual(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), pk_rounds, nt, calls,
+                                 E.ctypes.data, ss.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        return E, [bytes(r).decode() for r in ss], st
 
     def pf(self, seqs, nt=128):
         R, L = len(seqs), len(seqs[0])

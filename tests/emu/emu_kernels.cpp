@@ -3,12 +3,13 @@
 #include "hip_emu.h"
 
 thread_local emu_dim3 threadIdx;
-emu_dim3 blockIdx;
-emu_group* emu_g = nullptr;
+thread_local emu_dim3 blockIdx;
+thread_local emu_group* emu_g = nullptr;
 
 #include "../../desirna_amd/csrc/eval_structure.hpp"
 #include "../../desirna_amd/csrc/fold_mfe.hpp"
 #include "../../desirna_amd/csrc/fold_mfe_lds.hpp"
+#include "../../desirna_amd/csrc/fold_mfe_dual.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
 #include "../../desirna_amd/csrc/fold_outside.hpp"
@@ -29,6 +30,28 @@ Ctx* make_ctx(const int32_t* blob, int n, int max_L) {
   return c;
 }
 }  // namespace
+
+// two-workgroup MFE kernel: the main and the helper role of every sequence run side by side (2 x nt OS threads), exchanging
+// rows through ordinary memory with the same flags / epochs as on the GPU; `calls` repeats the batch to exercise the epochs
+template <int NT>
+static void run_mfe_dual(const MfeArgs& a, int R, int calls) {
+  const size_t rows = (size_t)2 * (MFE_FAST_NMAX + 2) * XP;
+  std::vector<int> flags((size_t)R * 64, 0);
+  std::vector<int32_t> xs((size_t)R * 256, 0), xa(rows * R, 0), xb(rows * R, 0);
+  auto* smA = new MfeFastSmem<NT>();
+  auto* smB = new MfeHelperSmem<NT>();
+  for (int call = 1; call <= calls; call++)
+    for (int r = 0; r < R; r++) {
+      DualLink lk;
+      lk.flagA = flags.data() + r * 64; lk.flagB = flags.data() + r * 64 + 32;
+      lk.xs = xs.data() + (size_t)r * 256; lk.xa = xa.data() + rows * r; lk.xb = xb.data() + rows * r; lk.epoch = call;
+      std::vector<std::function<void()>> fns;
+      fns.push_back([&, r, lk]() { mfe_lds_body<NT, true>(*smA, a, r, lk); });
+      fns.push_back([&, r, lk]() { mfe_helper<NT>(*smB, a, r, lk); });
+      emu_launch_many(2 * r, NT, fns);
+    }
+  delete smA; delete smB;
+}
 
 extern "C" {
 
@@ -56,6 +79,23 @@ int emu_mfe(const int32_t* blob, int n_int32, int R, int L, const char* seqs, in
   }
   if (dumpWc) std::memcpy(dumpWc, ws.data(), (size_t)ld * ld * 4);
   if (dumpFML) std::memcpy(dumpFML, ws.data() + (size_t)2 * ld * ld, (size_t)ld * ld * 4);
+  delete c;
+  return 0;
+}
+
+int emu_mfe_dual(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int pk_rounds, int nt, int calls, int32_t* Emfe,
+                 char* ss, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  std::vector<int32_t> ws((size_t)5 * ld * ld * R, 0);
+  MfeArgs a;
+  a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data();
+  a.seqs = seqs; a.L = L; a.ld = ld; a.pk_rounds = pk_rounds;
+  a.ws = ws.data(); a.ws_stride = (long long)5 * ld * ld;
+  a.Emfe = Emfe; a.ss = ss; a.status = status;
+  if (nt == 256) run_mfe_dual<256>(a, R, calls);
+  else run_mfe_dual<1024>(a, R, calls);
   delete c;
   return 0;
 }

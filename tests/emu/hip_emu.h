@@ -25,7 +25,7 @@
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };
 extern thread_local emu_dim3 threadIdx;
-extern emu_dim3 blockIdx;
+extern thread_local emu_dim3 blockIdx;     // per OS thread: two workgroups can be emulated side by side (emu_launch2)
 
 struct emu_wave {
   pthread_barrier_t bar;
@@ -35,7 +35,7 @@ struct emu_group {
   pthread_barrier_t bar;
   std::vector<emu_wave> waves;
 };
-extern emu_group* emu_g;
+extern thread_local emu_group* emu_g;
 
 static inline void __syncthreads() { pthread_barrier_wait(&emu_g->bar); }
 
@@ -114,23 +114,31 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 using std::min;
 using std::max;
 
+// run workgroups of nt threads each, all at the same time (one function per workgroup; block index = first + position)
+static inline void emu_launch_many(int first_block, int nt, const std::vector<std::function<void()>>& fns) {
+  std::vector<emu_group> gs(fns.size());
+  for (auto& g : gs) {
+    g.waves.resize(nt / 64);
+    pthread_barrier_init(&g.bar, nullptr, nt);
+    for (auto& w : g.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+  }
+  std::vector<std::thread> th;
+  th.reserve((size_t)nt * fns.size());
+  for (size_t b = 0; b < fns.size(); b++)
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([t, b, first_block, &gs, &fns]() {
+        threadIdx.x = t;
+        blockIdx.x = first_block + (int)b;
+        emu_g = &gs[b];
+        fns[b]();
+      });
+  for (auto& t : th) t.join();
+  for (auto& g : gs) {
+    pthread_barrier_destroy(&g.bar);
+    for (auto& w : g.waves) pthread_barrier_destroy(&w.bar);
+  }
+}
 // run one workgroup of nt threads executing fn()
 static inline void emu_launch(int block, int nt, const std::function<void()>& fn) {
-  emu_group g;
-  g.waves.resize(nt / 64);
-  pthread_barrier_init(&g.bar, nullptr, nt);
-  for (auto& w : g.waves) pthread_barrier_init(&w.bar, nullptr, 64);
-  emu_g = &g;
-  blockIdx.x = block;
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; t++)
-    th.emplace_back([t, &fn]() {
-      threadIdx.x = t;
-      fn();
-    });
-  for (auto& t : th) t.join();
-  pthread_barrier_destroy(&g.bar);
-  for (auto& w : g.waves) pthread_barrier_destroy(&w.bar);
-  emu_g = nullptr;
+  emu_launch_many(block, nt, std::vector<std::function<void()>>{fn});
 }

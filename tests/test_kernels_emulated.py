@@ -202,3 +202,22 @@ def test_kbest_structures_against_enumeration(emu, oracle):
                 assert oracle.eval_structure(s, x) == int(e), (s, x)    # each string has the energy reported for it
             else:
                 assert x == "." * len(s)
+
+
+@pytest.mark.parametrize("L,nt,pk", [(24, 256, 0), (41, 256, 3)])
+def test_two_workgroup_mfe_kernel(emu, oracle, L, nt, pk):
+    """fold_mfe_dual.hpp on the CPU: the main and the helper workgroup of every sequence run side by side (OS threads), rows
+    and flags go through ordinary memory; two calls in a row exercise the epoch arithmetic of the never-reset flags.
+    Energies and (pk-annotated) structures must equal the oracle's, a bad character must end both roles."""
+    rng = np.random.default_rng(900 + L)
+    seqs = ["".join(rng.choice(list("ACGU"), L))] + ["".join(rng.choice(list("GC"), L))]
+    E, ss, st = emu.mfe_dual(seqs, pk_rounds=pk, nt=nt, calls=2 if L == 24 else 1)
+    assert (st == 0).all()
+    for k, s in enumerate(seqs):
+        ref, e = oracle.mfe(s)
+        if pk:
+            ref = oracle.pk_struct(s, ref)
+        assert (ss[k], int(E[k])) == (ref, e), s
+    if L == 24:
+        _, _, st = emu.mfe_dual(["ACGUNACGUACGUACGUACGUACG"], nt=nt)
+        assert st[0] == 1
