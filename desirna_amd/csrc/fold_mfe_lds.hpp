@@ -756,9 +756,11 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
+          TOWER_PRIO(DRNA_TPRIO);
           const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG, lane)
                                : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG, lane);
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
+          TOWER_PRIO(0);
         }
         STAMP(0);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
