@@ -63,17 +63,6 @@ template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hi
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
-// The tower step is the critical path of a diagonal on the centre blocks: its waves get issue priority over the waves that
-// work through queue items on the same SIMD while it runs (s_setprio; DRNA_TPRIO=0 builds leave the arbitration alone)
-#ifndef DRNA_TPRIO
-#define DRNA_TPRIO 0
-#endif
-#ifdef DRNA_EMU
-#define TOWER_PRIO(p) do { } while (0)
-#else
-#define TOWER_PRIO(p) do { if (DRNA_TPRIO) __builtin_amdgcn_s_setprio(p); } while (0)
-#endif
-
 // wait until at most N of the wave's vector-memory operations are outstanding (they retire in issue order)
 template <int N>
 __device__ __forceinline__ void stores_in_flight() {
@@ -86,7 +75,7 @@ __device__ __forceinline__ void stores_in_flight() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-constexpr int SPIN_LIMIT = 1 << 18;
+constexpr int SPIN_LIMIT = 1 << 22;   // ~4 s of polling before a wait gives up (ST_SYNC): generous, a partner workgroup may queue behind other work
 #ifdef DRNA_DUALDBG
 #define DDBG(stmt) do { stmt; } while (0)
 #else

@@ -608,15 +608,19 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         const int32_t* row = PL + (k + 1) * ld;
         const int32_t* rowx = PLX + (k + 1) * ld;
         pw_cnt = row[ld - 1];
+        const int nch = (n - (k + 1) + WAVE - 1) >> 6;          // chunks the diagonal's cells can fill (uniform, known without the count)
 #pragma unroll
-        for (int c = 0; c < 4; c++) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
+        for (int c = 0; c < 4; c++)
+          if (c < nch) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
       }
       if (wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
+        const int nch = (j - TURN - 1 + WAVE - 1) >> 6;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const int i = lane + 1 + c * WAVE;
-          fx[c] = i <= j - TURN - 1 ? EXT[j * ld + i] : INF;
+          fx[c] = INF;
+          if (c < nch && i <= j - TURN - 1) fx[c] = EXT[j * ld + i];
         }
       }
       if (d > TURN) {
@@ -756,11 +760,9 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          TOWER_PRIO(DRNA_TPRIO);
           const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG, lane)
                                : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG, lane);
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
-          TOWER_PRIO(0);
         }
         STAMP(0);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);

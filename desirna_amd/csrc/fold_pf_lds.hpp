@@ -544,10 +544,8 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          TOWER_PRIO(DRNA_TPRIO);
           const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g, lane) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g, lane);
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
-          TOWER_PRIO(0);
         }
         STAMP(0);
         run_items(d);
