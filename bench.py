@@ -153,6 +153,8 @@ def roofline_block(dom, dom_ms, L, R, tk):
     except Exception:
         return out
     t = dom_ms * 1e-3
+    if k.get("kernel"):
+        out["kernel"] = k["kernel"].replace("void drna::", "").split("(")[0]
     bounds = {}
     if k.get("hbm_bytes_per_launch"):
         a = k["hbm_bytes_per_launch"] / t / 1e9

@@ -71,7 +71,7 @@ for k, d in raw.items():
     if key is None:
         continue
     out["raw"][k] = d
-    wgs = 64.0                                   # one workgroup = one CU per sequence
+    wgs = 128.0 if "dual" in k else 64.0         # one workgroup = one CU per sequence; two per sequence in the two-workgroup kernel
     e = {}
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         # MI355X_MICROARCH.md (HBM): both counters are KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2
@@ -89,6 +89,8 @@ for k, d in raw.items():
     if key in stats:
         e["rocprof_avg_ms"] = stats[key]["avg_ns"] * 1e-6
     e["clock_hz"] = 2.4e9
+    e["kernel"] = k
+    e["workgroups"] = wgs
     out["kernels"]["%s_L200_R64" % key] = e
 json.dump(out, open(os.path.join(G, "roofline_inputs.json"), "w"), indent=1)
 print(json.dumps({"units": units, "kernels": out["kernels"]}, indent=1))
