@@ -23,6 +23,7 @@
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
+#include "fold_pf_strip.hpp"
 #include "fold_subopt.hpp"
 #include "host_driver.hpp"
 #include "tables.hpp"
@@ -89,6 +90,10 @@ struct drna_engine {
   int dual_epoch = 0;             // grows by one per launch; flags are never reset (fold_common.hpp, DualLink)
   int* d_dflags = nullptr;        // [2 kernels][dual_cap][64]
   int32_t *d_xs = nullptr, *d_xa_mfe = nullptr, *d_xb_mfe = nullptr;
+  // strip kernels (fold_pf_strip.hpp: 200 < n <= 960, several workgroups per sequence): one flag line per (sequence, strip)
+  int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
+  int strip_epoch = 0;            // grows by one per call; flags are never reset
+  int* d_sflags = nullptr;        // [max_R][STRIP_MAXS][32]
   std::string err;
 };
 
@@ -112,6 +117,40 @@ static hipError_t upload(T** dst, const T* src, size_t count) {
 }
 
 static size_t mfe_ws_stride(int ld) { return (size_t)5 * ld * ld; }                       // int32
+
+// strips of a sequence of length n (0 = not a strip case): widest strip STRIP_WMAX columns; the exchange records of the
+// S - 1 strip boundaries must fit tables 0 and 1 of the sequence's workspace
+static int strips_for(const drna_engine* e, int n, int ld) {
+  if (!e->strips || !e->lds_path || e->nt != 1024 || n > STRIP_NMAX) return 0;
+  int S = 0;
+  if (n > PF_FAST_NMAX) S = strip_count(n, STRIP_WMAX);
+  else if (e->strips == 2 && n > 64) S = 2;
+  if (S < 2 || S > STRIP_MAXS) return 0;
+  if ((long long)(S - 1) * STRIP_REC > 2ll * ld) return 0;
+  return S;
+}
+
+// flags of the strip kernels: allocated (and zeroed, once) on first use; a new epoch per call
+static int strip_flags(drna_engine* e) {
+  if (!e->d_sflags) {
+    const size_t b = (size_t)e->max_R * STRIP_MAXS * 32 * sizeof(int);
+    HIP_TRY(hipMalloc((void**)&e->d_sflags, b));
+    HIP_TRY(hipMemset(e->d_sflags, 0, b));
+    e->strip_epoch = 0;
+  }
+  e->strip_epoch = (int)((unsigned)e->strip_epoch + 1u);
+  return DRNA_OK;
+}
+
+// nseq sequences (slots first_slot ...; idx = their sequence numbers or null) by S strips each
+static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
+  StripLink lk;
+  lk.flags = e->d_sflags + (size_t)first_slot * STRIP_MAXS * 32;
+  lk.base = (int)((unsigned)e->strip_epoch << 12);
+  lk.nseq = nseq; lk.S = S; lk.idx = idx;
+  const int groups = (nseq + 7) / 8;
+  hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * S), dim3(1024), 0, st, a, lk);
+}
 static size_t pf_ws_stride(int ld) { return (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8; }  // doubles
 
 static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int device, int max_R, int max_L) {
@@ -133,6 +172,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   e->cus = prop.multiProcessorCount;
   if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
+  if (const char* sv = getenv("DRNA_STRIPS")) { const int v = atoi(sv); e->strips = v < 0 ? 0 : v > 2 ? 2 : v; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
   HIP_TRY(upload(&e->d_plan, &e->H.plan, 1));
@@ -191,7 +231,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
                   e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss,
-                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
+                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -211,6 +251,7 @@ extern "C" void drna_destroy(drna_engine* e) {
 extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
+  if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
 }
@@ -286,7 +327,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
                         (L >= 170 || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
-      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
+      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags};
       for (void* b : old) if (b) (void)hipFree(b);
       e->d_dflags = nullptr; e->d_xs = nullptr; e->d_xa_mfe = nullptr; e->d_xb_mfe = nullptr;
       e->dual_cap = 0;
@@ -301,6 +342,10 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     }
     e->dual_epoch = (int)((unsigned)e->dual_epoch + 1u);           // never reset: flag compares are wrap-safe
   }
+  // longer sequences (and, as an option, short ones in small batches): the partition function by strips of columns, one
+  // workgroup each (fold_pf_strip.hpp)
+  const int pf_strips = want_pf ? strips_for(e, L, ld) : 0;
+  if (pf_strips) { const int rc = strip_flags(e); if (rc != DRNA_OK) return rc; }
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
   // previous call is enqueued first
@@ -311,7 +356,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
+    if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
+    else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
@@ -620,8 +666,9 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     e->err = "drna_score_ragged: bad argument (R within the engine's limit; output pointers for every requested flag)";
     return DRNA_ERR_ARG;
   }
-  // descriptors: len | off | target_of | index list of the LDS-resident kernels | index list of the general kernels
-  std::vector<int> h((size_t)5 * R);
+  // descriptors: len | off | target_of | index list of the LDS-resident kernels | of the general kernels | partition
+  // function only: of the strip kernels (longest first, i.e. by falling number of strips) | of the general kernel
+  std::vector<int> h((size_t)7 * R);
   int* off = h.data() + R;
   size_t total = 0;
   for (int r = 0; r < R; r++) {
@@ -645,19 +692,26 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
   const bool fast_ok = e->lds_path && e->nt == 1024;
   int nA = 0, nB = 0;
   int *idxA = h.data() + (size_t)3 * R, *idxB = h.data() + (size_t)4 * R;
+  int nC = 0, nD = 0;
+  int *idxC = h.data() + (size_t)5 * R, *idxD = h.data() + (size_t)6 * R;
+  const int ld = e->max_L + 2;
   for (int r : order) {
     if (fast_ok && lens[r] <= MFE_FAST_NMAX && lens[r] <= PF_FAST_NMAX) idxA[nA++] = r;
-    else idxB[nB++] = r;
+    else {
+      idxB[nB++] = r;
+      if (strips_for(e, lens[r], ld) && lens[r] > PF_FAST_NMAX) idxC[nC++] = r;
+      else idxD[nD++] = r;
+    }
   }
   HIP_TRY(hipSetDevice(e->device));
-  if (!e->d_rg) HIP_TRY(hipMalloc((void**)&e->d_rg, (size_t)5 * e->max_R * sizeof(int)));
+  if (!e->d_rg) HIP_TRY(hipMalloc((void**)&e->d_rg, (size_t)7 * e->max_R * sizeof(int)));
   HIP_TRY(hipMemcpy(e->d_rg, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_seqs, seqs, total, hipMemcpyHostToDevice));
   if (want_ev && R > 0) {
     if (!e->d_Ed) HIP_TRY(hipMalloc((void**)&e->d_Ed, (size_t)e->max_R * std::max(1, e->n_targets) * sizeof(int32_t)));
   }
-  const int ld = e->max_L + 2;
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
+  if (want_pf && nC) { const int rc = strip_flags(e); if (rc != DRNA_OK) return rc; }
   Ragged rg;
   rg.len = e->d_rg; rg.off = e->d_rg + R;
   const int* d_idxA = e->d_rg + (size_t)3 * R;
@@ -694,11 +748,19 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     a.Epf = e->d_Epf; a.status = e->d_status + e->max_R;
     a.rg = rg;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    if (nB) {
-      a.rg.idx = d_idxB;
-      if (e->nt == 256) launch_pf<256>(a, nB, e->s_pf);
-      else if (e->nt == 512) launch_pf<512>(a, nB, e->s_pf);
-      else launch_pf<1024>(a, nB, e->s_pf);
+    a.rg.idx = nullptr;
+    for (int k = 0; k < nC;) {                      // the strip kernel: one launch per number of strips, most strips first
+      const int S = strips_for(e, lens[idxC[k]], ld);
+      int m = k;
+      while (m < nC && strips_for(e, lens[idxC[m]], ld) == S) m++;
+      launch_pf_strips(e, a, m - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_pf);
+      k = m;
+    }
+    if (nD) {
+      a.rg.idx = e->d_rg + (size_t)6 * R;
+      if (e->nt == 256) launch_pf<256>(a, nD, e->s_pf);
+      else if (e->nt == 512) launch_pf<512>(a, nD, e->s_pf);
+      else launch_pf<1024>(a, nD, e->s_pf);
     }
     if (nA) {
       a.rg.idx = d_idxA;

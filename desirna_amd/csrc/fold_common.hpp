@@ -53,8 +53,8 @@ __device__ __forceinline__ int dual_done(int epoch) { return (int)((((unsigned)e
 __device__ __forceinline__ bool flag_ge(int v, int target) { return (int)((unsigned)v - (unsigned)target) >= 0; }
 
 #ifdef DRNA_EMU
-template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { T v; __atomic_load(p, &v, __ATOMIC_ACQUIRE); return v; }
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
 __device__ __forceinline__ void drain_vmem() {}
 __device__ __forceinline__ void spin_pause() { sched_yield(); }
 #else

@@ -71,9 +71,9 @@ __device__ __forceinline__ void pf_q5_column(PfFastSmem<NT>& sm, const double* _
   sm.q5[j] = sm.q5[j - 1] * sc1 + s;      // every lane stores the same value
 }
 
-template <int NT>
-__device__ __forceinline__ void pf_prepare_tables(PfFastSmem<NT>& sm, int d, int tid) {
-  constexpr int RS = PfFastSmem<NT>::RS;
+template <class SM>
+__device__ __forceinline__ void pf_prepare_tables(SM& sm, int d, int tid) {
+  constexpr int RS = SM::RS;
   if (tid >= 0 && tid < GRES) {
     // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
     //   G <- G * keep + (ring[A + i] + ring[B + i]) * asym;   contribution = G * size
@@ -104,8 +104,8 @@ __device__ __forceinline__ double lane_table_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-template <int NT, int R0, int R1>
-__device__ __forceinline__ double pf_tower_part(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int i8, int eA, int eB, double eas,
+template <class SM, int R0, int R1>
+__device__ __forceinline__ double pf_tower_part(const SM& sm, double (&G)[PGSLOTS], int i8, int eA, int eB, double eas,
                                                 double ekeep, double eW) {
   const char* ring = reinterpret_cast<const char*>(sm.qbi);
   double a[R1 - R0], b[R1 - R0];
@@ -123,16 +123,16 @@ __device__ __forceinline__ double pf_tower_part(const PfFastSmem<NT>& sm, double
   return acc;
 }
 
-template <int NT>
-__device__ __forceinline__ double pf_tower_step(const PfFastSmem<NT>& sm, double (&G)[PGSLOTS], int par, int i8, int g, int lane) {
+template <class SM>
+__device__ __forceinline__ double pf_tower_step(const SM& sm, double (&G)[PGSLOTS], int par, int i8, int g, int lane) {
   // lane r fetches the table entry of slot r (one LDS round trip for the wave); words are broadcast with v_readlane
   const int rr = lane * PNG + g;
   const bool on = lane < PGSLOTS && rr < GRES;
-  const int zero_row = 32 * PfFastSmem<NT>::RS * 8;
+  const int zero_row = 32 * SM::RS * 8;
   const int eA = on ? sm.tw_i[par][rr][0] : zero_row, eB = on ? sm.tw_i[par][rr][1] : zero_row;
   const double eas = on ? sm.tw_d[par][rr][0] : 0.0, ekeep = on ? sm.tw_d[par][rr][1] : 1.0, eW = on ? sm.tw_d[par][rr][2] : 0.0;
-  const double lo = pf_tower_part<NT, 0, PGSLOTS / 2>(sm, G, i8, eA, eB, eas, ekeep, eW);
-  const double hi = pf_tower_part<NT, PGSLOTS / 2, PGSLOTS>(sm, G, i8, eA, eB, eas, ekeep, eW);
+  const double lo = pf_tower_part<SM, 0, PGSLOTS / 2>(sm, G, i8, eA, eB, eas, ekeep, eW);
+  const double hi = pf_tower_part<SM, PGSLOTS / 2, PGSLOTS>(sm, G, i8, eA, eB, eas, ekeep, eW);
   return lo + hi;
 }
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   if (aw < 0) {
     const int d = TURN + 1;
     if (d < n) {
-      pf_prepare_tables<NT>(sm, d, tid);
+      pf_prepare_tables(sm, d, tid);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       // pairable list of diagonal k+1, exterior column j = k-3 (its cells were stored in step <= k-3 and drained by
       // that step's barrier)
       if (!(DRNA_SKIP & 32) && k + 1 < n) {
-        if (wave == w_tab) pf_prepare_tables<NT>(sm, k + 1, lane);
+        if (wave == w_tab) pf_prepare_tables(sm, k + 1, lane);
         if (wave == w_pl) {
           const int32_t* row = PL + (k + 1) * ld;
           const int cnt = row[ld - 1];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const double accG = par ? pf_tower_step<NT>(sm, GO, par, i * 8, my_g, lane) : pf_tower_step<NT>(sm, GE, par, i * 8, my_g, lane);
+          const double accG = par ? pf_tower_step(sm, GO, par, i * 8, my_g, lane) : pf_tower_step(sm, GE, par, i * 8, my_g, lane);
           sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
         }
         STAMP(0);

@@ -21,6 +21,7 @@ def build():
     L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_mfe_dual.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, vp, vp, vp]
+    L.emu_pf_strip.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, vp, vp]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
@@ -68,6 +69,16 @@ class Emu:
         st = np.zeros(R, dtype=np.int32)
         rc = self.L.emu_pf(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), nt,
                            E.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        return E, st
+
+    def pf_strip(self, seqs, S, nt=256, calls=1):
+        """partition function by S strips of columns, one workgroup each, side by side; returns (Epf, status)"""
+        R, L = len(seqs), len(seqs[0])
+        E = np.zeros(R)
+        st = np.zeros(R, dtype=np.int32)
+        rc = self.L.emu_pf_strip(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), nt, S, calls,
+                                 E.ctypes.data, st.ctypes.data)
         assert rc == 0
         return E, st
 

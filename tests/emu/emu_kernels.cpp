@@ -12,6 +12,7 @@ thread_local emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_mfe_dual.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
+#include "../../desirna_amd/csrc/fold_pf_strip.hpp"
 #include "../../desirna_amd/csrc/fold_outside.hpp"
 #include "../../desirna_amd/csrc/fold_cofold.hpp"
 #include "../../desirna_amd/csrc/fold_subopt.hpp"
@@ -53,7 +54,43 @@ static void run_mfe_dual(const MfeArgs& a, int R, int calls) {
   delete smA; delete smB;
 }
 
+// strip kernel of the partition function: the S strips of a sequence run side by side (S x nt OS threads) and hand their
+// records over through ordinary memory with the same flags / epochs as on the GPU; `calls` repeats the batch (epochs)
+template <int NT>
+static void run_pf_strip(const PfArgs& a, int R, int S, int calls) {
+  std::vector<int> flags((size_t)R * STRIP_MAXS * 32, 0);
+  std::vector<PfStripSmem<NT>*> sms;
+  for (int s = 0; s < S; s++) sms.push_back(new PfStripSmem<NT>());
+  for (int call = 1; call <= calls; call++)
+    for (int r = 0; r < R; r++) {
+      StripLink lk;
+      lk.flags = flags.data(); lk.base = call << 12; lk.nseq = R; lk.S = S;
+      std::vector<std::function<void()>> fns;
+      for (int s = 0; s < S; s++) fns.push_back([&, r, s, lk]() { pf_strip_body<NT>(*sms[s], a, lk, r, s); });
+      emu_launch_many(r * S, NT, fns);
+    }
+  for (auto* p : sms) delete p;
+}
+
 extern "C" {
+
+int emu_pf_strip(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int nt, int S, int calls, double* Epf,
+                 int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  const size_t stride = (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8;
+  std::vector<double> ws(stride * R, 0.0);
+  PfArgs a;
+  a.T = &c->H.pf; a.plan = &c->H.plan; a.hp_w = c->H.hp_w.data(); a.scale = c->H.scale.data();
+  a.eMLb = c->H.eMLb.data(); a.seqs = seqs; a.L = L; a.ld = ld;
+  a.ws = ws.data(); a.ws_stride = (long long)stride;
+  a.Epf = Epf; a.status = status;
+  if (nt == 256) run_pf_strip<256>(a, R, S, calls);
+  else run_pf_strip<1024>(a, R, S, calls);
+  delete c;
+  return 0;
+}
 
 // returns 0 on success.  tables (optional, may be null): Wc / FML dumps of the LAST sequence, ld*ld int32 each
 int emu_mfe(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int pk_rounds, int nt, int32_t* Emfe,

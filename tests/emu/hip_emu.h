@@ -17,6 +17,7 @@
 #include <vector>
 
 #define __device__
+#define __host__
 #define __global__
 #define __forceinline__ inline
 #define __shared__ static

@@ -636,3 +636,37 @@ def test_two_workgroup_mfe_equals_one_workgroup(eng400, oracle, eterna_targets):
             assert a["mfe_ss"][k] == ss and int(a["Emfe"][k]) == e
     with pytest.raises(E.EngineError):
         eng400.set_option("no-such-option", 1)
+
+
+def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
+    """Sequences longer than 200 nt are folded by strips of columns, one workgroup each (fold_pf_strip.hpp): the free energy of
+    the ensemble equals the general one-workgroup kernel's ("strips" off) and the oracle's to 1e-9 kcal/mol; two to four strips,
+    lengths at the strip-count boundaries, batches below and far above one workgroup per CU (workgroups then queue behind
+    each other: the strips of a sequence are dispatched upstream first), repeated calls (the flags are never reset), and the
+    two-strip form of a 200-nt batch bit for bit against the LDS-resident kernel (same summation order)."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(2400)
+    big = E.Engine(max_R=300, max_L=400, device=0)
+    for L, R in ((201, 5), (240, 64), (241, 9), (360, 30), (361, 8), (400, 128), (400, 300)):
+        seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
+        eng = big if R > 128 else eng400
+        try:
+            a = eng.score_batch(seqs, E.NEED_PF)["Epf"]
+            b = eng.score_batch(seqs, E.NEED_PF)["Epf"]
+            eng.set_option("strips", 0)
+            c = eng.score_batch(seqs, E.NEED_PF)["Epf"]
+        finally:
+            eng.set_option("strips", 1)
+        assert (a.view(np.int64) == b.view(np.int64)).all()
+        assert np.abs(a - c).max() < 1e-9
+        for k in (0, R - 1):
+            assert abs(a[k] - oracle.pf(seqs[k])) < 1e-9
+    big.close()
+    seqs = [_rand(rng, 200) for _ in range(64)]
+    try:
+        eng400.set_option("strips", 2)
+        a = eng400.score_batch(seqs, E.NEED_PF)["Epf"]
+    finally:
+        eng400.set_option("strips", 1)
+    c = eng400.score_batch(seqs, E.NEED_PF)["Epf"]
+    assert (a.view(np.int64) == c.view(np.int64)).all()

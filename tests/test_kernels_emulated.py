@@ -221,3 +221,15 @@ def test_two_workgroup_mfe_kernel(emu, oracle, L, nt, pk):
     if L == 24:
         _, _, st = emu.mfe_dual(["ACGUNACGUACGUACGUACGUACG"], nt=nt)
         assert st[0] == 1
+
+
+def test_pf_strip_kernel(emu, oracle):
+    """fold_pf_strip.hpp on the CPU: the three strips of every sequence run side by side (OS threads), records and flags go
+    through ordinary memory; the second call exercises the epoch arithmetic of the never-reset flags.  110 nt at 256 threads:
+    strips of 37 columns (a halo reaches 31), towers that walk through all three strips, multiloop sums dealt 1 / 2 / 4 ways."""
+    rng = np.random.default_rng(4110)
+    seqs = [_rand(rng, 110), _rand(rng, 110, "GC")]
+    Ep, st = emu.pf_strip(seqs, 3, nt=256, calls=2)
+    assert (st == 0).all()
+    for k, s in enumerate(seqs):
+        assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
