@@ -20,6 +20,7 @@
 #include "fold_cofold.hpp"
 #include "fold_mfe_lds.hpp"
 #include "fold_mfe_dual.hpp"
+#include "fold_mfe_strip.hpp"
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
 #include "fold_pf_lds.hpp"
@@ -93,7 +94,10 @@ struct drna_engine {
   // strip kernels (fold_pf_strip.hpp: 200 < n <= 960, several workgroups per sequence): one flag line per (sequence, strip)
   int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
   int strip_epoch = 0;            // grows by one per call; flags are never reset
-  int* d_sflags = nullptr;        // [max_R][STRIP_MAXS][32]
+  int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
+  int32_t* d_srec = nullptr;      // MFE strips: exchange records and list counts, srec_stride int32 per sequence
+  long long srec_stride = 0;
+  int* d_sdbg = nullptr;          // DRNA_STRIP_DEBUG=1: [2][max_R][8] words written by a strip whose wait failed
   std::string err;
 };
 
@@ -130,26 +134,57 @@ static int strips_for(const drna_engine* e, int n, int ld) {
   return S;
 }
 
-// flags of the strip kernels: allocated (and zeroed, once) on first use; a new epoch per call
-static int strip_flags(drna_engine* e) {
+// flags (and, for the MFE fold, the record buffer) of the strip kernels: allocated (flags zeroed, once) on first use
+static int strip_flags(drna_engine* e, bool mfe) {
   if (!e->d_sflags) {
-    const size_t b = (size_t)e->max_R * STRIP_MAXS * 32 * sizeof(int);
+    const size_t b = (size_t)2 * e->max_R * STRIP_MAXS * 32 * sizeof(int);
     HIP_TRY(hipMalloc((void**)&e->d_sflags, b));
     HIP_TRY(hipMemset(e->d_sflags, 0, b));
+    HIP_TRY(hipDeviceSynchronize());      // the memset runs on the null stream, the kernels on non-blocking streams of their own
     e->strip_epoch = 0;
+    if (getenv("DRNA_STRIP_DEBUG")) {
+      HIP_TRY(hipMalloc((void**)&e->d_sdbg, (size_t)2 * e->max_R * 8 * sizeof(int)));
+      HIP_TRY(hipMemset(e->d_sdbg, 0, (size_t)2 * e->max_R * 8 * sizeof(int)));
+      HIP_TRY(hipDeviceSynchronize());
+    }
   }
-  e->strip_epoch = (int)((unsigned)e->strip_epoch + 1u);
+  if (mfe && !e->d_srec) {
+    const int smax = strip_count(std::min(e->max_L, STRIP_NMAX), STRIP_WMAX);
+    e->srec_stride = (long long)std::max(smax, 2) * (e->max_L + 2) * MSTRIP_REC;
+    HIP_TRY(hipMalloc((void**)&e->d_srec, (size_t)e->srec_stride * e->max_R * sizeof(int32_t)));
+  }
   return DRNA_OK;
+}
+static int next_strip_epoch(drna_engine* e) {
+  e->strip_epoch = (int)((unsigned)e->strip_epoch + 1u);          // never reset: flag compares are wrap-safe
+  return (int)((unsigned)e->strip_epoch << 12);
 }
 
 // nseq sequences (slots first_slot ...; idx = their sequence numbers or null) by S strips each
 static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
   StripLink lk;
   lk.flags = e->d_sflags + (size_t)first_slot * STRIP_MAXS * 32;
-  lk.base = (int)((unsigned)e->strip_epoch << 12);
+  lk.base = next_strip_epoch(e);
   lk.nseq = nseq; lk.S = S; lk.idx = idx;
+  lk.dbg = e->d_sdbg ? e->d_sdbg + (size_t)first_slot * 8 : nullptr;
   const int groups = (nseq + 7) / 8;
   hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * S), dim3(1024), 0, st, a, lk);
+}
+
+// MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
+static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
+  StripRec xr;
+  xr.rec = e->d_srec; xr.stride = e->srec_stride;
+  const int groups = (nseq + 7) / 8;
+  for (int round = 0; round <= a.pk_rounds; round++) {
+    StripLink lk;
+    lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
+    lk.base = next_strip_epoch(e);
+    lk.nseq = nseq; lk.S = S; lk.idx = idx;
+    lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
+    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * S), dim3(1024), 0, st, a, lk, xr, round);
+    hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round);
+  }
 }
 static size_t pf_ws_stride(int ld) { return (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8; }  // doubles
 
@@ -231,7 +266,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
                   e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss,
-                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags};
+                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -327,13 +362,14 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
                         (L >= 170 || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
-      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags};
+      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg};
       for (void* b : old) if (b) (void)hipFree(b);
       e->d_dflags = nullptr; e->d_xs = nullptr; e->d_xa_mfe = nullptr; e->d_xb_mfe = nullptr;
       e->dual_cap = 0;
       const size_t rows = (size_t)2 * (MFE_FAST_NMAX + 2) * XP;
       HIP_TRY(hipMalloc((void**)&e->d_dflags, (size_t)2 * R * 64 * sizeof(int)));
       HIP_TRY(hipMemset(e->d_dflags, 0, (size_t)2 * R * 64 * sizeof(int)));
+      HIP_TRY(hipDeviceSynchronize());    // the memset runs on the null stream, the kernels on non-blocking streams of their own
       HIP_TRY(hipMalloc((void**)&e->d_xs, (size_t)R * 256 * sizeof(int32_t)));
       HIP_TRY(hipMalloc((void**)&e->d_xa_mfe, (size_t)R * rows * sizeof(int32_t)));
       HIP_TRY(hipMalloc((void**)&e->d_xb_mfe, (size_t)R * rows * sizeof(int32_t)));
@@ -345,7 +381,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // longer sequences (and, as an option, short ones in small batches): the partition function by strips of columns, one
   // workgroup each (fold_pf_strip.hpp)
   const int pf_strips = want_pf ? strips_for(e, L, ld) : 0;
-  if (pf_strips) { const int rc = strip_flags(e); if (rc != DRNA_OK) return rc; }
+  const int mfe_strips = want_mfe ? strips_for(e, L, ld) : 0;
+  if (pf_strips || mfe_strips) { const int rc = strip_flags(e, mfe_strips != 0); if (rc != DRNA_OK) return rc; }
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
   // previous call is enqueued first
@@ -382,7 +419,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       (void)hipMemsetAsync(lk.dbg, 0, 64 * 64 * sizeof(long long), e->s_mfe);
 #endif
       hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_mfe, a, lk);
-    } else if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
+    } else if (mfe_strips) launch_mfe_strips(e, a, R, mfe_strips, 0, nullptr, e->s_mfe);
+    else if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
       hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_mfe, a);
     else if (e->nt == 256) launch_mfe<256>(a, R, e->s_mfe);
     else if (e->nt == 512) launch_mfe<512>(a, R, e->s_mfe);
@@ -446,7 +484,16 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       e->err = buf;
       return DRNA_ERR_PF_RANGE;
     }
-    if (st == ST_SYNC) snprintf(buf, sizeof buf, "sequence %d: the two workgroups of the fold lost each other (a wait expired)", r);
+    if (st == ST_SYNC) {
+      snprintf(buf, sizeof buf, "sequence %d: the workgroups of the fold lost each other (a wait expired)", r);
+      if (e->d_sdbg) {
+        std::vector<int> dbg((size_t)2 * e->max_R * 8);
+        (void)hipMemcpy(dbg.data(), e->d_sdbg, dbg.size() * sizeof(int), hipMemcpyDeviceToHost);
+        for (size_t k = 0; k < dbg.size(); k += 8)
+          if (dbg[k]) fprintf(stderr, "strip debug slot %zu: strip %d step %d saw flag %d (base %d: %d) block %d n %d\n", k / 8, dbg[k] - 1, dbg[k + 1],
+                              dbg[k + 2], dbg[k + 3], dbg[k + 2] - dbg[k + 3], dbg[k + 4], dbg[k + 5]);
+      }
+    }
     else snprintf(buf, sizeof buf, "sequence %d: traceback could not reproduce a table value", r);
     e->err = buf;
     return DRNA_ERR_INTERNAL;
@@ -711,11 +758,10 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     if (!e->d_Ed) HIP_TRY(hipMalloc((void**)&e->d_Ed, (size_t)e->max_R * std::max(1, e->n_targets) * sizeof(int32_t)));
   }
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
-  if (want_pf && nC) { const int rc = strip_flags(e); if (rc != DRNA_OK) return rc; }
+  if ((want_pf || want_mfe) && nC) { const int rc = strip_flags(e, want_mfe); if (rc != DRNA_OK) return rc; }
   Ragged rg;
   rg.len = e->d_rg; rg.off = e->d_rg + R;
   const int* d_idxA = e->d_rg + (size_t)3 * R;
-  const int* d_idxB = e->d_rg + (size_t)4 * R;
   HIP_TRY(hipEventRecord(e->ev_start, e->s_mfe));
   HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_start, 0));
   HIP_TRY(hipStreamWaitEvent(e->s_eval, e->ev_start, 0));
@@ -727,11 +773,19 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     a.Emfe = e->d_Emfe; a.ss = e->d_ss; a.status = e->d_status;
     a.rg = rg;
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
-    if (nB) {                                       // the long sequences first
-      a.rg.idx = d_idxB;
-      if (e->nt == 256) launch_mfe<256>(a, nB, e->s_mfe);
-      else if (e->nt == 512) launch_mfe<512>(a, nB, e->s_mfe);
-      else launch_mfe<1024>(a, nB, e->s_mfe);
+    a.rg.idx = nullptr;
+    for (int k = 0; k < nC;) {                      // the long sequences first: strip kernels, one launch per number of strips
+      const int S = strips_for(e, lens[idxC[k]], ld);
+      int m = k;
+      while (m < nC && strips_for(e, lens[idxC[m]], ld) == S) m++;
+      launch_mfe_strips(e, a, m - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_mfe);
+      k = m;
+    }
+    if (nD) {
+      a.rg.idx = e->d_rg + (size_t)6 * R;
+      if (e->nt == 256) launch_mfe<256>(a, nD, e->s_mfe);
+      else if (e->nt == 512) launch_mfe<512>(a, nD, e->s_mfe);
+      else launch_mfe<1024>(a, nD, e->s_mfe);
     }
     if (nA) {
       a.rg.idx = d_idxA;

@@ -245,4 +245,60 @@ __device__ __forceinline__ int rtype_of(int t) {
   return (int)((lut >> (t * 4)) & 15u);
 }
 
+// ---- strip kernels (fold_pf_strip.hpp, fold_mfe_strip.hpp): one sequence folded by several workgroups, each owning a strip
+// of columns i; dependencies between strips run one way (towards smaller i), see fold_pf_strip.hpp
+#ifndef STRIP_DIAG
+#define STRIP_DIAG 0     // diagnostic builds only (timing; results wrong): 1 plain table stores, 2 plain multiloop loads, 4 no waits / records in,
+#endif                   // 8 barrier without store drain, 16 no record exports
+constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
+constexpr int STRIP_REC = 88;                         // doubles per exchange record
+constexpr int STRIP_MAXS = 8;                         // strips per sequence at most
+constexpr int STRIP_WMAX = 120;                       // widest strip of the production kernel (1024 threads)
+constexpr int STRIP_NMAX = STRIP_MAXS * STRIP_WMAX;   // longest sequence
+
+struct StripLink {
+  int* flags = nullptr;      // one 128-byte line per (sequence slot, strip)
+  int base = 0;              // epoch << 12
+  int nseq = 0;              // sequences of this launch
+  int S = 0;                 // strips per sequence
+  const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null
+  int* dbg = nullptr;        // diagnostics: 8 words per sequence slot, written by a strip whose wait failed
+};
+__host__ __device__ inline int strip_count(int n, int wmax) { return (n + wmax - 1) / wmax; }
+__host__ __device__ inline int strip_width(int n, int S) { return (n + S - 1) / S; }
+
+struct StripRec {              // MFE strips: exchange records and list counts live in a buffer of their own
+  int32_t* rec = nullptr;
+  long long stride = 0;        // int32 per sequence
+};
+// wait until the strip's flag shows diagonal `target` (or DONE / FAIL); one wave, every lane returns the same value
+__device__ __forceinline__ bool strip_wait(const int* flag, int base, int d, int& seen) {
+  const int target = base + d;
+  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+    const int v = __builtin_amdgcn_readfirstlane(ld_agent(flag));
+    seen = v;
+    if (flag_ge(v, target)) return v != base + STRIP_FAIL;
+    spin_pause();
+  }
+  return false;
+}
+
+#if STRIP_DIAG & 8
+#define STRIP_BARRIER() lds_barrier()
+#else
+#define STRIP_BARRIER() __syncthreads()
+#endif
+template <typename T> __device__ __forceinline__ void strip_store(T* p, T v) {
+#if STRIP_DIAG & 1
+  *p = v;
+#else
+  st_agent(p, v);
+#endif
+}
+template <typename RS>
+__device__ __forceinline__ f64x2 buf_load_f64x2_sc1(RS rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);     // aux 16 = sc1: bypasses this CU's L1
+  return f64x2{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
+}
+
 }  // namespace drna

@@ -105,9 +105,11 @@ __device__ __forceinline__ void mfe_f5_column(MfeFastSmem<NT>& sm, const int32_t
 // Per-diagonal table for diagonal d (written by a finalize wave one step ahead, so the sweep waves spend
 // no scalar instructions on offsets): residue rho of an inner diagonal -> ring offsets and size terms of
 // the tower entry that lives there on diagonal d.
-template <int NT>
-__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio, int emode = E_ALL) {
-  constexpr int RS = MfeFastSmem<NT>::RS;
+template <class SM>
+__device__ __forceinline__ void mfe_prepare_etab(SM& sm, int d, int lane, int mode);
+template <class SM>
+__device__ __forceinline__ void mfe_prepare_tower_tab(SM& sm, int d, int tid, int ninio, int max_ninio) {
+  constexpr int RS = SM::RS;
   const int par = d & 1;
   if (tid >= 0 && tid < GRES) {
     // entry of the tower slot whose inner diagonal is congruent to tid (mod 28), as seen from diagonal d:
@@ -130,13 +132,17 @@ __device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, i
     int* e = sm.tower_tab[par][tid];
     e[0] = offA; e[1] = offB; e[2] = as; e[3] = fl; e[4] = L; e[5] = 0;
   }
+}
+template <int NT>
+__device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio, int emode = E_ALL) {
+  mfe_prepare_tower_tab(sm, d, tid, ninio, max_ninio);
   if (tid >= 0 && tid < WAVE) mfe_prepare_etab(sm, d, tid, emode);
 }
 
 // one diagonal step of the register-resident generic-interior minima of a tower (branch-free, table-driven);
 // returns the generic candidate (without the outer mismatch term) for the cell at column i
-template <int NT>
-__device__ __forceinline__ int mfe_tower_step(const MfeFastSmem<NT>& sm, int (&G)[GSLOTS], int par, int i4, int g, int NG, int lane) {
+template <class SM>
+__device__ __forceinline__ int mfe_tower_step(const SM& sm, int (&G)[GSLOTS], int par, int i4, int g, int NG, int lane) {
   const char* ring = reinterpret_cast<const char*>(sm.ciring);
   // lane r fetches the table entry of slot r (one LDS round trip for the whole wave); the words are then
   // broadcast with v_readlane as they are needed -- no per-slot LDS read, no scalarised loads
@@ -376,17 +382,16 @@ __device__ __forceinline__ void mfe_init_eshape(SM& sm, const MfeTables& T, int 
 // staged values or from another table of xtab.  (The shape-uniform items of mfe_e_item need a third of the instructions but
 // more items per diagonal; with sixteen waves sharing one work queue this form is faster up to n = 200: 0.245 vs 0.281 ms at
 // n = 100, equal at 200.)
-template <int NT>
-__device__ __forceinline__ void mfe_e_item_rows(MfeFastSmem<NT>& sm, int e, int d, int par, int pcnt, int slot0, int lane, int TermAU,
-                                                int e_bulge1, int e_int23) {
-  constexpr int RS = MfeFastSmem<NT>::RS;
+template <class SM>
+__device__ __forceinline__ void mfe_e_item_rows(SM& sm, int e, int d, int par, int pcnt, int slot0, int lane, int TermAU,
+                                                int e_bulge1, int e_int23, int slot_mask = -1) {
+  constexpr int RS = SM::RS;
   const int INF = INF_DEV, HALF = INF_DEV / 2;
   const int it = e, nK = 0;
   // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots in registers, the
   // row minimum takes four DPP steps for all four cells at once, lane 15 of each row is the only writer.
   // Slots 3 and 7 of some lanes are the nine small shapes (see the eshape table): same ring read, but the
   // energy comes from the cell's staged values or from another table of xtab.
-  using SM = MfeFastSmem<NT>;
   const int q = 4 * (it - nK) + (lane >> 4);
   const int qc = q < pcnt ? q : pcnt - 1;
   const int pe = sm.plist[par][qc], xv = sm.xe[par][qc];
@@ -437,7 +442,7 @@ __device__ __forceinline__ void mfe_e_item_rows(MfeFastSmem<NT>& sm, int e, int 
   v = dpp_min_i32<0x112, 0xF>(v);
   v = dpp_min_i32<0x114, 0xF>(v);
   v = dpp_min_i32<0x118, 0xF>(v);
-  if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][i0 + slot0], v);
+  if ((lane & 15) == 15 && q < pcnt && v < HALF) atomicMin(&sm.accI[par][(i0 + slot0) & slot_mask], v);
 }
 
 // Structure of one diagonal step k (ONE workgroup barrier per diagonal):
@@ -760,8 +765,8 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
         if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
           int i = my_tb * WAVE + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const int accG = par ? mfe_tower_step<NT>(sm, GO, par, i * 4, my_g, NG, lane)
-                               : mfe_tower_step<NT>(sm, GE, par, i * 4, my_g, NG, lane);
+          const int accG = par ? mfe_tower_step(sm, GO, par, i * 4, my_g, NG, lane)
+                               : mfe_tower_step(sm, GE, par, i * 4, my_g, NG, lane);
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
         }
         STAMP(0);
@@ -789,7 +794,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 #endif
           } else {
             if (DUAL) mfe_e_item<E_NEAR>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
-            else mfe_e_item_rows<NT>(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
+            else mfe_e_item_rows(sm, it - nK, d, par, pcnt, slot0, lane, TermAU, e_bulge1, e_int23);
             STAMP(1);
 #ifdef DRNA_STAMPS
             st_acc[2]++;

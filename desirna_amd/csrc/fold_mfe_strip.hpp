@@ -1,0 +1,589 @@
+// fold_mfe_strip.hpp -- Zuker MFE fill of ONE sequence by SEVERAL workgroups, each keeping its share of the rings in LDS
+// like fold_mfe_lds.hpp: the path for 200 < n <= 960.  Same recursions, same outputs and the same traceback as fold_mfe.hpp
+// (reference utils/energy_scores.py:151,354).  The decomposition is the one of fold_pf_strip.hpp --
+// strips of columns i, dependencies one way, one exchange record per diagonal and strip boundary, tower minima that walk from
+// strip to strip -- with the min-plus algebra of fold_mfe_lds.hpp:
+//   record of diagonal d (96 int32): [0,32) ring words (c + TermAU) * 256 + info of the strip's first 32 columns,
+//   [32,64) their c + mismatchI words, [64,94) the tower minima (3 waves x 10 entries) of the tower that leaves the strip,
+//   94 fML and 95 the decomposition minimum of the first column.
+// fML cannot stay in LDS here (the multiloop splits read all of it): it goes to the sequence's table 2 in HBM/L2 like the
+// general kernel's, stored write-through, and the split items read it from there (16 bytes = four adjacent cells per lane).
+// A pseudoknot round is ONE launch of the fill (mfe_strip_kernel) followed by ONE launch of the traceback
+// (mfe_strip_trace_kernel, one wave per sequence, on the tables the strips left in HBM): the kernel boundary is the hand-over,
+// the structure found so far (the output string itself) is the state that masks the next round.
+#pragma once
+#include "fold_mfe_lds.hpp"
+
+namespace drna {
+
+constexpr int MSTRIP_REC = 96;        // int32 per exchange record
+
+template <int NT>
+struct MfeStripSmem {
+  static constexpr int NW = NT / WAVE;
+  static constexpr int P = NT >= 1024 ? 128 : 64;        // physical tower lanes
+  static constexpr int WMAX = P - 8;                     // widest strip
+  static constexpr int RS = WMAX + 34;                   // ring row pitch: own columns 1..wid, halo wid+1..wid+32
+  static constexpr int NL = WMAX + 8;
+  static constexpr int NFIN = P / WAVE;                  // finalize waves
+  static constexpr int NSVC = NT >= 1024 ? 2 : 0;        // service waves; else finalize wave 0 does their jobs
+  static constexpr int NG = 3;                           // tower waves per block of 64 towers
+  static constexpr int XT_STACK = 0, XT_INT11 = 64, XT_MM1N = 64 + 1024, XT_MM23 = 64 + 1024 + 128;
+  int stack[64];
+  int mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128];
+  int int11[1024];
+  int d5[32], d3[32];
+  int f5[STRIP_NMAX + 2];
+  int hpl[STRIP_NMAX + 2];
+  int wring[33 * RS];            // (c + TermAU(inner type)) * 256 + info of the last 32 diagonals; row 32 stays INF
+  int ciring[32 * RS];           // c + mismatchI(inner side)
+  int dml[4 * RS];               // decomposition minima of the last 4 diagonals
+  int fmlrow[2][RS];             // fML of the last two diagonals
+  int accG[2][P], accI[2][P], accK[2][P];
+  int gimp[2][NG][GSLOTS + 2];   // minima of the tower that enters the strip, staged by the service wave
+  int xtab[64 + 1024 + 128 + 128];
+  int plist[2][NL];
+  int xe[2][NL];
+  int pcnt[2];
+  int qk[2], qe[2];
+  int eshape_rows[128];
+  int tw_L[32];
+  int tower_tab[2][32][6];
+  unsigned char S[STRIP_NMAX + 4];
+  unsigned char Sp[STRIP_NMAX + 4];
+  int flag;
+  int sync_fail[2];
+};
+
+template <typename RSRC>
+__device__ __forceinline__ i32x4 buf_load_i32x4_sc1(RSRC rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);
+  return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+
+// one diagonal step of a tower wave: import of the tower that enters the strip, the recurrence, export of the one that leaves
+template <class SM>
+__device__ __forceinline__ void mstrip_tower(SM& sm, int (&G)[GSLOTS], int d, int wid, int n_loc, int phys, int my_tb, int my_g,
+                                             int lane, bool has_up, bool has_down, int32_t* rec_out) {
+  constexpr int P = SM::P;
+  const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
+  const int iraw = ((phys - sh - 1) & (P - 1)) + 1;
+  const bool live = iraw <= ncell;
+  const int i = live ? iraw : 1;
+  const int pe = (wid + sh) & (P - 1);
+  if (has_up && ncell == wid && d - 2 > TURN && (pe >> 6) == my_tb) {
+    const bool mine = lane == (pe & (WAVE - 1));
+#pragma unroll
+    for (int qx = 0; qx < GSLOTS; qx++) {
+      const int v = sm.gimp[par][my_g][qx];
+      G[qx] = mine ? v : G[qx];
+    }
+  }
+  const int accG = mfe_tower_step(sm, G, par, i * 4, my_g, SM::NG, lane);
+  if (live) atomicMin(&sm.accG[par][phys], accG);
+  if (!(STRIP_DIAG & 16) && has_down && live && iraw == 1) {
+    int32_t* rec = rec_out + (long long)d * MSTRIP_REC + 64 + my_g * GSLOTS;
+#pragma unroll
+    for (int qx = 0; qx < GSLOTS; qx++) st_agent(rec + qx, (int32_t)G[qx]);
+  }
+}
+
+// one strip of one sequence, one round.  q = sequence slot of the launch, s = strip (0 = highest columns)
+template <int NT>
+__device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, StripRec xr, int q, int s, int round) {
+  using SM = MfeStripSmem<NT>;
+  constexpr int NW = SM::NW, RS = SM::RS, P = SM::P, NFIN = SM::NFIN, NSVC = SM::NSVC, NG = SM::NG;
+  const MfeTables& T = *A.T;
+  const int r = lk.idx ? lk.idx[q] : q;
+  if (A.rg.len) A.L = A.rg.len[r];
+  const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;
+  const int n = A.L, ld = A.ld;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  const int INF = INF_DEV, HALF = INF_DEV / 2;
+  const int ninio = T.ninio, max_ninio = T.max_ninio, MLbase = T.MLbase, MLclosing = T.MLclosing,
+            MLintern = T.MLintern, TermAU = T.TermAU;
+  const int S = lk.S;
+  const int wfull = strip_width(n, S);
+  const int t_ = S - 1 - s;
+  const int c0 = t_ * wfull + 1;
+  if (c0 > n) return;
+  const int c1 = min(n, (t_ + 1) * wfull);
+  const int wid = c1 - c0 + 1, n_loc = n - c0 + 1;
+  const bool has_up = c1 < n, has_down = c0 > 1, last = !has_down;
+  const int n_loc_up = n_loc - wid;
+  int* const my_flag = lk.flags + ((long long)q * STRIP_MAXS + s) * 32;
+  const int* const up_flag = lk.flags + ((long long)q * STRIP_MAXS + (s > 0 ? s - 1 : 0)) * 32;
+
+  int32_t* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  int32_t* Wc = base;                 // row 0: state word (see mfe_strip_trace_kernel), row 1: f5
+  int32_t* PLX = base + 1 * tab;
+  int32_t* FML = base + 2 * tab;
+  int32_t* PL = base + 3 * tab;
+  int32_t* EXT = base + 4 * tab;
+  int32_t* const xbase = xr.rec + (long long)r * xr.stride;
+  int32_t* const rec_out = xbase + (long long)s * ld * MSTRIP_REC;
+  const int32_t* const rec_in = xbase + (long long)(s > 0 ? s - 1 : 0) * ld * MSTRIP_REC;
+  int32_t* const PLC = xbase + (long long)(S - 1) * ld * MSTRIP_REC;      // list counts: [d * 8 + s]
+
+  // later rounds run only for sequences whose previous round found a pair (state word 1, written by the traceback kernel)
+  if (round > 0 && Wc[0] != 1) return;
+
+  // ---- prologue: tables
+  for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
+  for (int k = tid; k < 128; k += NT) {
+    sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
+    sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
+  }
+  for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
+  for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  if (tid == 0) { sm.flag = 0; sm.sync_fail[0] = 0; sm.sync_fail[1] = 0; }
+  __syncthreads();
+  // local sequence and pairing codes (4 = may not pair: positions paired in an earlier round, and both ends)
+  const char* seq = A.seqs + so;
+  for (int k = tid; k <= n_loc + 1; k += NT) {
+    int g = c0 - 1 + k;
+    const bool inside = g >= 1 && g <= n;
+    g = g < 1 ? n : (g > n ? 1 : g);
+    const int c = enc_nt(seq[g - 1]);
+    sm.S[k] = (unsigned char)(c < 0 ? 0 : c);
+    int p = c < 0 ? 4 : c;
+    if (!inside) p = 4;
+    else if (round > 0 && A.ss[so + g - 1] != '.') p = 4;
+    sm.Sp[k] = (unsigned char)p;
+  }
+  for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
+  for (int k = tid; k < 2 * RS; k += NT) (&sm.fmlrow[0][0])[k] = INF;
+  for (int k = tid; k < 32 * RS; k += NT) { sm.wring[k] = INF * 256; sm.ciring[k] = INF; }
+  for (int k = tid; k < RS; k += NT) sm.wring[32 * RS + k] = INF * 256;
+  for (int k = tid; k <= n; k += NT) sm.hpl[k] = A.hp_len[k];
+  for (int k = tid; k < P; k += NT)
+    for (int p = 0; p < 2; p++) { sm.accG[p][k] = INF; sm.accI[p][k] = INF; sm.accK[p][k] = INF; }
+  for (int k = tid; k < 2 * NG * (GSLOTS + 2); k += NT) (&sm.gimp[0][0][0])[k] = INF;
+  for (int x = tid; x < 128; x += NT) {
+    // shape slots of the 16-lane-row E items (see mfe_fill_lds)
+    int s_, u1_, L_, kind_ = 0;
+    if (x < 64) {
+      const bool on = x < 58;
+      u1_ = (x < 29 || !on) ? 0 : x - 27;
+      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
+      L_ = on ? T.bulge[s_] : 0x3fff;
+      if (x >= 58 && x <= 60) { kind_ = x - 53; s_ = x == 60 ? 4 : 3; u1_ = x == 58 ? 1 : 2; L_ = 0; }
+    } else {
+      const int y = x - 64;
+      const bool on = y < 54;
+      u1_ = (y < 27 || !on) ? 1 : y - 24;
+      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
+      const int nl = s_ - 1;
+      L_ = on ? T.interior[nl + 1] + min(max_ninio, (nl - 1) * ninio) : 0x3fff;
+      if (y >= 54 && y <= 59) {
+        const int z = y - 54;
+        kind_ = z == 0 ? 1 : z <= 2 ? 2 : z == 3 ? 3 : 4;
+        s_ = z == 0 ? 0 : z <= 2 ? 1 : z == 3 ? 2 : 5;
+        u1_ = z <= 1 ? 0 : z <= 3 ? 1 : z - 2;
+        L_ = 0;
+      }
+    }
+    sm.eshape_rows[x] = s_ | (kind_ << 5) | (u1_ << 8) | (L_ << 16);
+  }
+  for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
+  __syncthreads();
+  for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
+  for (int k = tid; k < 1024; k += NT) sm.xtab[SM::XT_INT11 + k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
+  for (int k = tid; k < 128; k += NT) {
+    sm.xtab[SM::XT_MM1N + k] = sm.mm1n[k] - ((k >> 4) > 2 ? TermAU : 0);
+    sm.xtab[SM::XT_MM23 + k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
+  }
+  if (last) for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
+  // compacted list of the strip's pairable cells of every diagonal, with the staged (1,2) / (2,1) / (2,2) loop energies
+  for (int d = TURN + 1 + wave; d < n_loc; d += NW) {
+    const int nc = min(wid, n_loc - d);
+    int cntb = 0;
+    for (int i0 = 1; i0 <= nc; i0 += WAVE) {
+      const int i = i0 + lane;
+      int t = 0;
+      if (i <= nc) t = pair_type(sm.Sp[i], sm.Sp[i + d]);
+      const unsigned long long m = __ballot(t != 0);
+      if (t) {
+        const int pos = cntb + __popcll(m & ((1ull << lane) - 1ull));
+        const int j = i + d, si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+        const bool va = d - 5 > TURN, vc = d - 6 > TURN;
+        const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
+                  tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
+        const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
+        const int s_ip2 = sm.S[i + 2], s_jm2 = sm.S[j - 2];
+        const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
+        const int eb = T.int21[tb ? (rb * 8 + t) * 64 + sj1 * 16 + si1 * 4 + s_ip2 : 0];
+        const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
+        const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
+                  cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
+        PL[d * ld + c0 - 1 + pos] = (i | ((t * 16 + si1 * 4 + sj1) << 8)) | (cc << 15);
+        PLX[d * ld + c0 - 1 + pos] = (a & 0xffff) | (b << 16);
+      }
+      cntb += __popcll(m);
+    }
+    if (lane == 0) PLC[d * STRIP_MAXS + s] = cntb;
+  }
+  __syncthreads();
+
+  // roles
+  const int w_svcA = NSVC ? NFIN : 0, w_svcB = NSVC ? NFIN + 1 : 0;
+  const int aw = wave - NFIN - NSVC;
+  const int my_tb = aw >= 0 ? aw / NG : NFIN, my_g = aw >= 0 ? aw - my_tb * NG : 0;
+  const bool pinned = aw >= 0 && my_tb < NFIN;
+  const bool fin = wave < NFIN;
+
+  if (wave == w_svcA) {
+    const int d = TURN + 1;
+    if (d < n_loc) mfe_prepare_tower_tab(sm, d, lane, ninio, max_ninio);
+  }
+  if (wave == w_svcB) {
+    const int d = TURN + 1;
+    if (d < n_loc) {
+      const int cnt = PLC[d * STRIP_MAXS + s];
+      for (int k = lane; k < cnt; k += WAVE) { sm.plist[d & 1][k] = PL[d * ld + c0 - 1 + k]; sm.xe[d & 1][k] = PLX[d * ld + c0 - 1 + k]; }
+      if (lane == 0) { sm.pcnt[d & 1] = cnt; sm.qk[0] = 0; sm.qk[1] = 0; sm.qe[0] = 0; sm.qe[1] = 0; }
+    }
+  }
+  __syncthreads();
+
+  const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)(tab * 4), 0x00020000);
+  const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
+
+  // floating work items of diagonal d: multiloop splits from L2 (64 cells x 4 split-point groups per item, four adjacent cells
+  // per lane; a block's split points are dealt to 1, 2, 4 or 8 items as the sums grow), then the bulge / 1xn / small shapes
+  auto run_items = [&](const int d, auto with_k) {
+    const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
+    const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+    const int kssh = d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0;
+    const int KS = 1 << kssh, KG = 4 << kssh;
+    const int astep = 4 * KG * ld, cstep = 4 * KG * (ld - 1);
+    const int nK = ((ncell + 63) >> 6) << kssh, nE = (pcnt + 3) >> 2;
+    const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
+    auto pop = [&]() -> int {
+      if (decltype(with_k)::value) {
+        const int it = queue_pop(&sm.qk[par], lane);
+        if (it < nK) return it;
+      }
+      return nK + queue_pop(&sm.qe[par], lane);
+    };
+    for (int it = pop(); it < nItems; it = pop()) {
+      if (decltype(with_k)::value && it < nK) {
+        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+        int i = ((it >> kssh) << 6) + 4 * cl + 1;
+        const bool act = i <= ncell;
+        i = act ? i : 1;
+        const int ig = i + c0 - 1;
+        int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
+        int tt = TURN + 1 + g;
+        const int tmax = d - TURN - 2;
+        int vA = (tt * ld + ig) * 4;                               // fML[i .. i+3, . + tt]
+        int vC = ((d - tt - 1) * ld + ig + tt + 1) * 4;            // fML[i+tt+1 .. , j ..]
+        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
+          const int vCl = vC - 3 * cstep;
+          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vCl, 3 * cstep);
+          const i32x4 a1 = buf_load_i32x4(rsF, vA, astep), c1v = buf_load_i32x4_sc1(rsF, vCl, 2 * cstep);
+          const i32x4 a2 = buf_load_i32x4(rsF, vA, 2 * astep), c2v = buf_load_i32x4_sc1(rsF, vCl, cstep);
+          const i32x4 a3 = buf_load_i32x4(rsF, vA, 3 * astep), c3v = buf_load_i32x4_sc1(rsF, vCl, 0);
+          vA += 4 * astep; vC -= 4 * cstep;
+          m0 = min(m0, min(min(a0.x + c0v.x, a1.x + c1v.x), min(a2.x + c2v.x, a3.x + c3v.x)));
+          m1 = min(m1, min(min(a0.y + c0v.y, a1.y + c1v.y), min(a2.y + c2v.y, a3.y + c3v.y)));
+          m2 = min(m2, min(min(a0.z + c0v.z, a1.z + c1v.z), min(a2.z + c2v.z, a3.z + c3v.z)));
+          m3 = min(m3, min(min(a0.w + c0v.w, a1.w + c1v.w), min(a2.w + c2v.w, a3.w + c3v.w)));
+        }
+        for (; tt <= tmax; tt += KG) {
+          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vC, 0);
+          m0 = min(m0, a0.x + c0v.x); m1 = min(m1, a0.y + c0v.y); m2 = min(m2, a0.z + c0v.z); m3 = min(m3, a0.w + c0v.w);
+          vA += astep; vC -= cstep;
+        }
+        // the four 16-lane rows hold different split points of the same cells
+        m0 = min(m0, __shfl_xor(m0, 16)); m1 = min(m1, __shfl_xor(m1, 16)); m2 = min(m2, __shfl_xor(m2, 16)); m3 = min(m3, __shfl_xor(m3, 16));
+        m0 = min(m0, __shfl_xor(m0, 32)); m1 = min(m1, __shfl_xor(m1, 32)); m2 = min(m2, __shfl_xor(m2, 32)); m3 = min(m3, __shfl_xor(m3, 32));
+        if (lane < 16 && act) {
+          if (m0 < HALF) atomicMin(&sm.accK[par][(i + sh) & (P - 1)], m0);
+          if (i + 1 <= ncell && m1 < HALF) atomicMin(&sm.accK[par][(i + 1 + sh) & (P - 1)], m1);
+          if (i + 2 <= ncell && m2 < HALF) atomicMin(&sm.accK[par][(i + 2 + sh) & (P - 1)], m2);
+          if (i + 3 <= ncell && m3 < HALF) atomicMin(&sm.accK[par][(i + 3 + sh) & (P - 1)], m3);
+        }
+      } else {
+        mfe_e_item_rows(sm, it - nK, d, par, pcnt, sh, lane, TermAU, e_bulge1, e_int23, P - 1);
+      }
+    }
+  };
+
+  // ---- service jobs of step k
+  // A: the record of diagonal k-1 of the strip above (ring halo, fML / decomposition minimum of its first column, the minima of
+  //    the tower that enters at diagonal k+1); tower table of diagonal k+1
+  auto service_a = [&](const int k) {
+    if (!(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1) {
+      int seen = 0;
+      if (!strip_wait(up_flag, lk.base, k - 1, seen)) {
+        sm.sync_fail[k & 1] = 1;
+        if (lane == 0 && lk.dbg) { int* g = lk.dbg + q * 8; g[0] = s + 1; g[1] = k; g[2] = seen; g[3] = lk.base; g[4] = (int)blockIdx.x; g[5] = n; }
+      }
+      else {
+        const int dd = k - 1;
+        const int32_t* rec = rec_in + (long long)dd * MSTRIP_REC;
+        const int w0 = ld_agent(rec + lane);                            // lanes 0..31 ring words, 32..63 c + mismatchI words
+        const int g0 = lane < 32 ? ld_agent(rec + 64 + lane) : 0;       // tower minima (30), fML, decomposition minimum
+        if (lane < 32) sm.wring[(dd & 31) * RS + wid + 1 + lane] = w0;
+        else sm.ciring[(dd & 31) * RS + wid + 1 + lane - 32] = w0;
+        if (lane < NG * GSLOTS) sm.gimp[(k + 1) & 1][lane / GSLOTS][lane % GSLOTS] = g0;
+        if (lane == 30) sm.fmlrow[dd & 1][wid + 1] = g0;
+        if (lane == 31) sm.dml[(dd & 3) * RS + wid + 1] = g0;
+      }
+    }
+    if (k + 1 < n_loc) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
+  };
+  // B: pairable list of diagonal k+1; exterior column j = k-3 (last strip)
+  auto service_b = [&](const int k) {
+    if (k + 1 < n_loc) {
+      const int dn = k + 1;
+      const int cnt = PLC[dn * STRIP_MAXS + s];
+      const int32_t* row = PL + dn * ld + c0 - 1;
+      const int32_t* rowx = PLX + dn * ld + c0 - 1;
+      const int p0 = lane < cnt ? row[lane] : 0, p1 = lane + WAVE < cnt ? row[lane + WAVE] : 0;
+      const int x0 = lane < cnt ? rowx[lane] : 0, x1 = lane + WAVE < cnt ? rowx[lane + WAVE] : 0;
+      sm.plist[dn & 1][lane] = p0; sm.xe[dn & 1][lane] = x0;
+      if (lane + WAVE < SM::NL) { sm.plist[dn & 1][lane + WAVE] = p1; sm.xe[dn & 1][lane + WAVE] = x1; }
+      if (lane == 0) { sm.pcnt[dn & 1] = cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
+    }
+    if (last && k - 3 >= TURN + 2) {
+      const int j = k - 3;
+      int m = INF;
+      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
+        const int x = ld_agent(&EXT[j * ld + i]);
+        if (x < HALF) m = min(m, sm.f5[i - 1] + x);
+      }
+      m = wave_min_i32(m);
+      const int prev = sm.f5[j - 1];
+      sm.f5[j] = prev < m ? prev : m;
+    }
+  };
+
+  bool failed = false;
+  if (fin) {
+    // ================= finalize waves: diagonal d = k-1 at step k
+    for (int k = TURN + 1; k <= n_loc; k++) {
+      const int d = k - 1;
+      if (tid == 0 && has_down && k - 2 > TURN) st_agent(my_flag, lk.base + k - 2);
+      if (d > TURN) {
+        const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
+        const int i = ((tid - sh - 1) & (P - 1)) + 1;
+        const int dm1v = as_vector(d - 1);
+        if (i <= ncell) {
+          const int aG = sm.accG[par][tid], aI = sm.accI[par][tid], aK = sm.accK[par][tid];
+          sm.accG[par][tid] = INF; sm.accI[par][tid] = INF; sm.accK[par][tid] = INF;
+          const int j = i + d;
+          const int ig = i + c0 - 1, jg = ig + d;
+          const int t = pair_type(sm.Sp[i], sm.Sp[j]);
+          const int tau = t > 2 ? TermAU : 0;
+          int c = INF, info = 0, cb = INF;
+          if (t) {
+            const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
+            c = mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
+            c = min(c, aI);
+            c = min(c, aG + sm.mmI[ij]);
+            const int dmlv = sm.dml[((d - 2) & 3) * RS + i + 1];
+            if (dmlv < HALF)
+              c = min(c, dmlv + MLclosing + MLintern + tau + sm.mmM[rtype_of(t) * 16 + sm.S[j - 1] * 4 + sm.S[i + 1]]);
+            if (c >= HALF) c = INF;
+            info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
+            cb = c < INF ? c + tau : INF;
+          }
+          const int ww = cb * 256 + info, cw = c < INF ? c + sm.mmI[info] : INF;
+          sm.wring[(d & 31) * RS + i] = ww;
+          sm.ciring[(d & 31) * RS + i] = cw;
+          Wc[d * ld + ig] = c * 256 + info;
+          int est = 0;                                    // E_ExtLoop(type, i > 1 ? S[i-1] : -1, j < n ? S[j+1] : -1), dangles = 2
+          if (t) {
+            if (ig > 1 && jg < n) est = sm.mmExt[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]];
+            else if (ig > 1) est = sm.d5[t * 4 + sm.S[i - 1]];
+            else if (jg < n) est = sm.d3[t * 4 + sm.S[j + 1]];
+          }
+          strip_store(&EXT[jg * ld + ig], (int32_t)(c < INF ? c + tau + est : INF));
+          int f = INF;
+          if (d - 1 > TURN) {
+            const int fa = sm.fmlrow[(d - 1) & 1][i + 1], fb = sm.fmlrow[(d - 1) & 1][i];
+            if (fa < HALF) f = fa + MLbase;
+            if (fb < HALF) f = min(f, fb + MLbase);
+          }
+          if (c < INF) f = min(f, c + MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
+          const int dec = aK >= HALF ? INF : aK;
+          sm.dml[(d & 3) * RS + i] = dec;
+          const int fv = min(f, dec);
+          sm.fmlrow[d & 1][i] = fv;
+          strip_store(&FML[d * ld + ig], (int32_t)fv);
+          if (!(STRIP_DIAG & 16) && has_down && i <= 32) {
+            int32_t* rec = rec_out + (long long)d * MSTRIP_REC;
+            st_agent(rec + (i - 1), (int32_t)ww);
+            st_agent(rec + 32 + (i - 1), (int32_t)cw);
+            if (i == 1) { st_agent(rec + 94, (int32_t)fv); st_agent(rec + 95, (int32_t)dec); }
+          }
+        }
+      }
+      if (!NSVC && wave == 0) { service_a(k); service_b(k); }
+      if (k < n_loc) run_items(k, std::true_type{});
+      STRIP_BARRIER();
+      if (sm.sync_fail[k & 1]) { failed = true; break; }
+    }
+  } else if (NSVC && wave < NFIN + NSVC) {
+    // ================= service waves
+    for (int k = TURN + 1; k <= n_loc; k++) {
+      if (wave == w_svcA) service_a(k); else service_b(k);
+      if (k < n_loc) run_items(k, std::true_type{});
+      STRIP_BARRIER();
+      if (sm.sync_fail[k & 1]) { failed = true; break; }
+    }
+  } else if (!pinned) {
+    // ================= floating waves: items only
+    for (int k = TURN + 1; k <= n_loc; k++) {
+      if (k < n_loc) run_items(k, std::true_type{});
+      STRIP_BARRIER();
+      if (sm.sync_fail[k & 1]) { failed = true; break; }
+    }
+  } else {
+    // ================= tower waves: diagonal d = k at step k, then shape items
+    int GE[GSLOTS], GO[GSLOTS];
+#pragma unroll
+    for (int qx = 0; qx < GSLOTS; qx++) { GE[qx] = INF; GO[qx] = INF; }
+    const int phys = my_tb * WAVE + lane;
+    static_assert(((TURN + 1) & 1) == 0, "the loop below starts on an even diagonal");
+    for (int k = TURN + 1; k <= n_loc; k += 2) {
+      if (k < n_loc) {
+        mstrip_tower(sm, GE, k, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        run_items(k, std::false_type{});
+      }
+      STRIP_BARRIER();
+      if (sm.sync_fail[k & 1]) { failed = true; break; }
+      if (k + 1 > n_loc) break;
+      if (k + 1 < n_loc) {
+        mstrip_tower(sm, GO, k + 1, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        run_items(k + 1, std::false_type{});
+      }
+      STRIP_BARRIER();
+      if (sm.sync_fail[(k + 1) & 1]) { failed = true; break; }
+    }
+  }
+
+  if (failed) {
+    if (tid == 0) {
+      if (has_down) st_agent(my_flag, lk.base + STRIP_FAIL);
+      else { A.status[r] = ST_SYNC; Wc[0] = -1; }
+    }
+    return;
+  }
+  if (has_down) {
+    if (tid == 0) st_agent(my_flag, lk.base + STRIP_DONE);
+    return;
+  }
+  // last strip: the remaining exterior columns; f5 and the state word go to the traceback kernel
+  if (wave == 0) {
+    for (int j = max(TURN + 2, n - 2); j <= n; j++) {
+      int m = INF;
+      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
+        const int x = ld_agent(&EXT[j * ld + i]);
+        if (x < HALF) m = min(m, sm.f5[i - 1] + x);
+      }
+      m = wave_min_i32(m);
+      const int prev = sm.f5[j - 1];
+      sm.f5[j] = prev < m ? prev : m;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k <= n; k += NT) Wc[ld + k] = sm.f5[k];
+  if (tid == 0) Wc[0] = 2;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
+  __shared__ MfeStripSmem<NT> sm;
+  const int b = blockIdx.x, per = 8 * lk.S;
+  const int grp = b / per, x = b - grp * per;
+  const int q = grp * 8 + (x & 7), s = x >> 3;
+  if (q >= lk.nseq) return;
+  mfe_strip_body<NT>(sm, A, lk, xr, q, s, round);
+}
+
+// traceback of one round, one wave per sequence, on the tables the strips of that round left in HBM (a launch of its own: the
+// kernel boundary makes them visible).  State word Wc[0]: 2 = the fill of this round is done (written by the last strip),
+// -1 = a strip lost its neighbour; this kernel leaves 1 if another round follows for the sequence, else 0.
+struct MfeTraceSmem : MfeSmemCore<STRIP_NMAX> {};
+
+__device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const int* idx, int q, int round) {
+  const int r = idx ? idx[q] : q;
+  if (A.rg.len) A.L = A.rg.len[r];
+  const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;
+  const int n = A.L, ld = A.ld, lane = lane_id();
+  const MfeTables& T = *A.T;
+  int32_t* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  int32_t* Wc = base;
+  const int32_t* FML = base + 2 * tab;
+  const int32_t* EXT = base + 4 * tab;
+  const int state = Wc[0];
+  if (round > 0 && state != 2) return;                 // no fill this round: the sequence was finished earlier
+  for (int k = lane; k < 64; k += WAVE) sm.stack[k] = T.stack[k];
+  for (int k = lane; k < 128; k += WAVE) {
+    sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
+    sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
+  }
+  for (int k = lane; k < 1024; k += WAVE) sm.int11[k] = T.int11[k];
+  for (int k = lane; k < 32; k += WAVE) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  if (lane == 0) sm.flag = 0;
+  const char* seq = A.seqs + so;
+  for (int k = lane; k < n; k += WAVE) {
+    const int c = enc_nt(seq[k]);
+    if (c < 0) sm.flag = 1;
+    sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
+    const char prev = round > 0 ? A.ss[so + k] : '.';
+    sm.sspk[k] = prev;
+    sm.Sp[k + 1] = (unsigned char)(c < 0 || prev != '.' ? 4 : c);
+    sm.ssw[k] = '.';
+  }
+  for (int k = lane; k <= n; k += WAVE) sm.f5[k] = Wc[ld + k];
+  if (lane == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; sm.Sp[0] = 4; sm.Sp[n + 1] = 4; }
+  __syncthreads();
+  if (sm.flag) {
+    if (lane == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; Wc[0] = 0; }
+    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = '.';
+    return;
+  }
+  if (state != 2) {                                    // round 0 and the fill failed (ST_SYNC is already in the status word)
+    if (lane == 0) { A.Emfe[r] = 0; Wc[0] = 0; }
+    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = '.';
+    return;
+  }
+  const bool ok = mfe_traceback(sm, A, Wc, FmlGlobal{FML, ld}, EXT);
+  __syncthreads();
+  if (!ok) {
+    if (lane == 0) { A.status[r] = ST_TRACEBACK; Wc[0] = 0; if (round == 0) A.Emfe[r] = sm.f5[n]; }
+    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = sm.sspk[k];
+    return;
+  }
+  const char op = round == 0 ? '(' : round == 1 ? '[' : round == 2 ? '<' : '{';
+  const char cl = round == 0 ? ')' : round == 1 ? ']' : round == 2 ? '>' : '}';
+  int any = 0;
+  for (int k = lane; k < n; k += WAVE) {
+    const char ch = sm.ssw[k];
+    if (ch == '(') { sm.sspk[k] = op; any = 1; }
+    else if (ch == ')') sm.sspk[k] = cl;
+    A.ss[so + k] = sm.sspk[k];
+  }
+  const bool any_w = __ballot(any != 0) != 0ull;
+  if (lane == 0) {
+    if (round == 0) A.Emfe[r] = sm.f5[n];
+    A.status[r] = ST_OK;
+    // reference sequence_utils.py:1194,1210: the next re-fold happens only if this one found a pair
+    Wc[0] = ((round == 0 || any_w) && round < A.pk_rounds) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void mfe_strip_trace_kernel(MfeArgs A, const int* idx, int nseq, int round) {
+  __shared__ MfeTraceSmem sm;
+  if ((int)blockIdx.x >= nseq) return;
+  mfe_strip_trace_body(sm, A, idx, blockIdx.x, round);
+}
+
+}  // namespace drna

@@ -30,25 +30,6 @@
 
 namespace drna {
 
-#ifndef STRIP_DIAG
-#define STRIP_DIAG 0     // diagnostic builds only (timing; results wrong): 1 plain table stores, 2 plain multiloop loads, 4 no waits / records in,
-#endif                   // 8 barrier without store drain, 16 no record exports
-constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
-constexpr int STRIP_REC = 88;                         // doubles per exchange record
-constexpr int STRIP_MAXS = 8;                         // strips per sequence at most
-constexpr int STRIP_WMAX = 120;                       // widest strip of the production kernel (1024 threads)
-constexpr int STRIP_NMAX = STRIP_MAXS * STRIP_WMAX;   // longest sequence
-
-struct StripLink {
-  int* flags = nullptr;      // one 128-byte line per (sequence slot, strip)
-  int base = 0;              // epoch << 12
-  int nseq = 0;              // sequences of this launch
-  int S = 0;                 // strips per sequence
-  const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null
-};
-__host__ __device__ inline int strip_count(int n, int wmax) { return (n + wmax - 1) / wmax; }
-__host__ __device__ inline int strip_width(int n, int S) { return (n + S - 1) / S; }
-
 template <int NT>
 struct PfStripSmem {
   static constexpr int NW = NT / WAVE;
@@ -84,35 +65,6 @@ struct PfStripSmem {
   int flag;
   int sync_fail[2];      // by step parity: set by the service wave during step k, read by everybody after the barrier of step k
 };
-
-// wait until the strip's flag shows diagonal `target` (or DONE / FAIL); one wave, every lane returns the same value
-__device__ __forceinline__ bool strip_wait(const int* flag, int base, int d, int& seen) {
-  const int target = base + d;
-  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
-    const int v = __builtin_amdgcn_readfirstlane(ld_agent(flag));
-    if (flag_ge(v, target)) { seen = v; return v != base + STRIP_FAIL; }
-    spin_pause();
-  }
-  return false;
-}
-
-#if STRIP_DIAG & 8
-#define STRIP_BARRIER() lds_barrier()
-#else
-#define STRIP_BARRIER() __syncthreads()
-#endif
-template <typename T> __device__ __forceinline__ void strip_store(T* p, T v) {
-#if STRIP_DIAG & 1
-  *p = v;
-#else
-  st_agent(p, v);
-#endif
-}
-template <typename RS>
-__device__ __forceinline__ f64x2 buf_load_f64x2_sc1(RS rsrc, int voff, int soff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);     // aux 16 = sc1: bypasses this CU's L1
-  return f64x2{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
-}
 
 // one diagonal step of a tower wave: import of the tower that enters the strip, the recurrence, export of the one that leaves
 template <class SM>
@@ -433,7 +385,10 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   auto service_a = [&](const int k) {
     if (!(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1) {
       int seen = 0;
-      if (!strip_wait(up_flag, lk.base, k - 1, seen)) { sm.sync_fail[k & 1] = 1; }
+      if (!strip_wait(up_flag, lk.base, k - 1, seen)) {
+        sm.sync_fail[k & 1] = 1;
+        if (lane == 0 && lk.dbg) { int* g = lk.dbg + q * 8; g[0] = s + 1; g[1] = k; g[2] = seen; g[3] = lk.base; g[4] = (int)blockIdx.x; g[5] = n; }
+      }
       else {
         const int dd = k - 1;
         const double* rec = rec_in + (long long)dd * STRIP_REC;

@@ -10,6 +10,7 @@ thread_local emu_group* emu_g = nullptr;
 #include "../../desirna_amd/csrc/fold_mfe.hpp"
 #include "../../desirna_amd/csrc/fold_mfe_lds.hpp"
 #include "../../desirna_amd/csrc/fold_mfe_dual.hpp"
+#include "../../desirna_amd/csrc/fold_mfe_strip.hpp"
 #include "../../desirna_amd/csrc/fold_pf.hpp"
 #include "../../desirna_amd/csrc/fold_pf_lds.hpp"
 #include "../../desirna_amd/csrc/fold_pf_strip.hpp"
@@ -72,7 +73,52 @@ static void run_pf_strip(const PfArgs& a, int R, int S, int calls) {
   for (auto* p : sms) delete p;
 }
 
+// strip kernel of the MFE fold: per pseudoknot round the S strips of a sequence side by side, then the traceback "launch"
+template <int NT>
+static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls) {
+  std::vector<int> flags((size_t)R * STRIP_MAXS * 32, 0);
+  StripRec xr;
+  xr.stride = (long long)S * a.ld * MSTRIP_REC;
+  std::vector<int32_t> rec((size_t)xr.stride * R, 0);
+  xr.rec = rec.data();
+  std::vector<MfeStripSmem<NT>*> sms;
+  for (int s = 0; s < S; s++) sms.push_back(new MfeStripSmem<NT>());
+  auto* smt = new MfeTraceSmem();
+  int epoch = 0;
+  for (int call = 1; call <= calls; call++)
+    for (int round = 0; round <= a.pk_rounds; round++) {
+      epoch++;
+      for (int r = 0; r < R; r++) {
+        StripLink lk;
+        lk.flags = flags.data(); lk.base = epoch << 12; lk.nseq = R; lk.S = S;
+        std::vector<std::function<void()>> fns;
+        for (int s = 0; s < S; s++) fns.push_back([&, r, s, lk, round]() { mfe_strip_body<NT>(*sms[s], a, lk, xr, r, s, round); });
+        emu_launch_many(r * S, NT, fns);
+      }
+      for (int r = 0; r < R; r++) emu_launch(r, 64, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round); });
+    }
+  for (auto* p : sms) delete p;
+  delete smt;
+}
+
 extern "C" {
+
+int emu_mfe_strip(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int pk_rounds, int nt, int S, int calls,
+                  int32_t* Emfe, char* ss, int32_t* status) {
+  Ctx* c = make_ctx(blob, n_int32, L);
+  if (!c->ok) { delete c; return -1; }
+  const int ld = L + 2;
+  std::vector<int32_t> ws((size_t)5 * ld * ld * R, 0);
+  MfeArgs a;
+  a.T = &c->H.mfe; a.plan = &c->H.plan; a.hp_len = c->H.hp_len.data();
+  a.seqs = seqs; a.L = L; a.ld = ld; a.pk_rounds = pk_rounds;
+  a.ws = ws.data(); a.ws_stride = (long long)5 * ld * ld;
+  a.Emfe = Emfe; a.ss = ss; a.status = status;
+  if (nt == 256) run_mfe_strip<256>(a, R, S, calls);
+  else run_mfe_strip<1024>(a, R, S, calls);
+  delete c;
+  return 0;
+}
 
 int emu_pf_strip(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int nt, int S, int calls, double* Epf,
                  int32_t* status) {

@@ -639,34 +639,45 @@ def test_two_workgroup_mfe_equals_one_workgroup(eng400, oracle, eterna_targets):
 
 
 def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
-    """Sequences longer than 200 nt are folded by strips of columns, one workgroup each (fold_pf_strip.hpp): the free energy of
-    the ensemble equals the general one-workgroup kernel's ("strips" off) and the oracle's to 1e-9 kcal/mol; two to four strips,
-    lengths at the strip-count boundaries, batches below and far above one workgroup per CU (workgroups then queue behind
-    each other: the strips of a sequence are dispatched upstream first), repeated calls (the flags are never reset), and the
-    two-strip form of a 200-nt batch bit for bit against the LDS-resident kernel (same summation order)."""
+    """Sequences longer than 200 nt are folded by strips of columns, one workgroup each (fold_pf_strip.hpp, fold_mfe_strip.hpp):
+    MFE energies and structures (pseudoknot rounds included) equal the general one-workgroup kernels' ("strips" off) and the
+    oracle's bit for bit, the ensemble free energy to 1e-9 kcal/mol; two to four strips, lengths at the strip-count boundaries,
+    batches below and far above one workgroup per CU (workgroups then queue behind each other: the strips of a sequence are
+    dispatched upstream first), repeated calls (the flags are never reset), and the two-strip form of a 200-nt batch against
+    the LDS-resident kernels (Epf bit for bit: same summation order)."""
     from desirna_amd import engine as E
     rng = np.random.default_rng(2400)
     big = E.Engine(max_R=300, max_L=400, device=0)
-    for L, R in ((201, 5), (240, 64), (241, 9), (360, 30), (361, 8), (400, 128), (400, 300)):
+    for L, R, pk in ((201, 5, True), (240, 64, False), (241, 9, True), (360, 30, False), (361, 8, True), (400, 128, True), (400, 300, False)):
         seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
         eng = big if R > 128 else eng400
+        flags = E.NEED_PF | E.NEED_MFE | (E.NEED_PK if pk else 0)
         try:
-            a = eng.score_batch(seqs, E.NEED_PF)["Epf"]
-            b = eng.score_batch(seqs, E.NEED_PF)["Epf"]
+            a = eng.score_batch(seqs, flags)
+            b = eng.score_batch(seqs, flags)
             eng.set_option("strips", 0)
-            c = eng.score_batch(seqs, E.NEED_PF)["Epf"]
+            c = eng.score_batch(seqs, flags)
         finally:
             eng.set_option("strips", 1)
-        assert (a.view(np.int64) == b.view(np.int64)).all()
-        assert np.abs(a - c).max() < 1e-9
+        assert (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all()
+        assert np.abs(a["Epf"] - c["Epf"]).max() < 1e-9
+        assert a["mfe_ss"] == b["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == c["Emfe"]).all() and (a["Emfe"] == b["Emfe"]).all()
         for k in (0, R - 1):
-            assert abs(a[k] - oracle.pf(seqs[k])) < 1e-9
+            assert abs(a["Epf"][k] - oracle.pf(seqs[k])) < 1e-9
+            ss, e = oracle.mfe(seqs[k])
+            if pk:
+                ss = oracle.pk_struct(seqs[k], ss)
+            assert a["mfe_ss"][k] == ss and int(a["Emfe"][k]) == e
     big.close()
     seqs = [_rand(rng, 200) for _ in range(64)]
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_PK
     try:
         eng400.set_option("strips", 2)
-        a = eng400.score_batch(seqs, E.NEED_PF)["Epf"]
+        a = eng400.score_batch(seqs, flags)
     finally:
         eng400.set_option("strips", 1)
-    c = eng400.score_batch(seqs, E.NEED_PF)["Epf"]
-    assert (a.view(np.int64) == c.view(np.int64)).all()
+    c = eng400.score_batch(seqs, flags)
+    assert (a["Epf"].view(np.int64) == c["Epf"].view(np.int64)).all()
+    assert a["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == c["Emfe"]).all()
+    with pytest.raises(E.EngineError):                   # a bad character is reported by the strip path too
+        eng400.score_batch(["ACGU" * 60 + "N" + "ACGU" * 2], E.NEED_MFE | E.NEED_PF)

@@ -224,12 +224,27 @@ def test_two_workgroup_mfe_kernel(emu, oracle, L, nt, pk):
 
 
 def test_pf_strip_kernel(emu, oracle):
-    """fold_pf_strip.hpp on the CPU: the three strips of every sequence run side by side (OS threads), records and flags go
+    """fold_pf_strip.hpp on the CPU: the three strips of a sequence run side by side (OS threads), records and flags go
     through ordinary memory; the second call exercises the epoch arithmetic of the never-reset flags.  110 nt at 256 threads:
     strips of 37 columns (a halo reaches 31), towers that walk through all three strips, multiloop sums dealt 1 / 2 / 4 ways."""
     rng = np.random.default_rng(4110)
-    seqs = [_rand(rng, 110), _rand(rng, 110, "GC")]
+    seqs = [_rand(rng, 110, "GGCCAU")]
     Ep, st = emu.pf_strip(seqs, 3, nt=256, calls=2)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
         assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
+
+
+def test_mfe_strip_kernel(emu, oracle):
+    """fold_mfe_strip.hpp on the CPU: per pseudoknot round the two strips of a sequence side by side, then the traceback
+    "launch" on the tables they left behind; energies and pk-annotated structures must equal the oracle's; a bad character is
+    reported by the traceback kernel."""
+    rng = np.random.default_rng(4111)
+    seqs = [_rand(rng, 100, "GGCCAU")]
+    E, ss, st = emu.mfe_strip(seqs, 2, pk_rounds=3, nt=256, calls=1)
+    assert (st == 0).all()
+    for k, s in enumerate(seqs):
+        ref, e = oracle.mfe(s)
+        assert (ss[k], int(E[k])) == (oracle.pk_struct(s, ref), e), s
+    _, ss, st = emu.mfe_strip(["ACGUN" * 20], 2, nt=256)
+    assert st[0] == 1 and ss[0] == "." * 100
