@@ -176,6 +176,7 @@ static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S,
   StripRec xr;
   xr.rec = e->d_srec; xr.stride = e->srec_stride;
   const int groups = (nseq + 7) / 8;
+  if (e->d_sdbg) fprintf(stderr, "mfe strips: rec %p stride %lld max_R %d nseq %d S %d ld %d L %d ws %p\n", (void*)xr.rec, xr.stride, e->max_R, nseq, S, a.ld, a.L, (void*)a.ws);
   for (int round = 0; round <= a.pk_rounds; round++) {
     StripLink lk;
     lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
@@ -362,7 +363,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
                         (L >= 170 || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
-      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg};
+      void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};
       for (void* b : old) if (b) (void)hipFree(b);
       e->d_dflags = nullptr; e->d_xs = nullptr; e->d_xa_mfe = nullptr; e->d_xb_mfe = nullptr;
       e->dual_cap = 0;

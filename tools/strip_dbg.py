@@ -1,17 +1,17 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import bench
 from desirna_amd import engine as E
-rng = np.random.default_rng(11)
-L, R = 400, 64
-seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
-eng = E.Engine(max_R=R, max_L=L)
-for it in range(30):
-    t = time.time()
-    try:
-        eng.score_batch(seqs, E.NEED_PF)
-    except Exception as ex:
-        print("iter", it, "FAILED after %.2f s" % (time.time() - t), ex, flush=True)
-        break
-else:
-    print("30 calls ok", eng.last_timing())
+tg = bench.load_target("eteV1_53.txt"); L = len(tg)
+rng = np.random.default_rng(5)
+def _rand(rng, L, a="ACGU"): return "".join(rng.choice(list(a), L))
+seqs = [_rand(rng, L) for _ in range(6)] + [_rand(rng, L, "GGCCAU") for _ in range(2)]
+eng = E.Engine(max_R=128, max_L=400)
+eng.set_targets([tg, tg, tg])
+for name, flags in (("pf", E.NEED_PF), ("mfe", E.NEED_MFE), ("mfe+pk", E.NEED_MFE | E.NEED_PK), ("mfe+pk+pf", E.NEED_MFE | E.NEED_PK | E.NEED_PF),
+                    ("all", E.NEED_MFE | E.NEED_PK | E.NEED_PF | E.NEED_EVAL)):
+    print("case", name, flush=True)
+    for it in range(3):
+        eng.score_batch(seqs, flags)
+    print("  ok", eng.last_timing(), flush=True)
