@@ -496,8 +496,13 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   if (tid == 0) Wc[0] = 2;
 }
 
+#ifdef MSTRIP_WAVES8
+#define MSTRIP_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))     // 64 VGPRs: two workgroups per CU
+#else
+#define MSTRIP_ATTR
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
+__global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
   __shared__ MfeStripSmem<NT> sm;
   const int b = blockIdx.x, per = 8 * lk.S;
   const int grp = b / per, x = b - grp * per;

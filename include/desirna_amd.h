@@ -171,6 +171,10 @@ int drna_last_edef_timing(const drna_engine *e, float out[2]);
  * the MFE fold of every sequence of at least 170 nt is done by TWO workgroups (fold_mfe_dual.hpp).  Results do not depend
  * on it (integer minima: bit-identical).  0 = always one workgroup per sequence, 2 = two workgroups whenever the batch allows,
  * whatever the length.  DRNA_DUAL in the environment sets the default.
+ * "strips" (default 1): sequences of 201 .. 960 nt are folded by strips of columns, one workgroup per strip of <= 120 columns
+ * (fold_pf_strip.hpp, fold_mfe_strip.hpp), in drna_score_batch* and drna_score_ragged.  MFE energies and structures do not
+ * depend on it (bit-identical), Epf agrees to 1e-13 kcal/mol (another summation order).  0 = the general one-workgroup kernels,
+ * 2 = two strips also for 64 < n <= 200 (diagnostics).  DRNA_STRIPS in the environment sets the default.
  */
 int drna_set_option(drna_engine *e, const char *name, int value);
 

@@ -14,7 +14,8 @@ for k, a in enumerate(sys.argv[1:]):
 for p in procs:
     p.wait()
 rng = np.random.default_rng(11)
-cases = [(200, 64), (400, 64), (400, 128)]
+cases = [(400, 64), (400, 128), (400, 256)]
+WHAT = os.environ.get("WHAT", "pf")
 seqs = {c: ["".join(rng.choice(list("ACGU"), c[0])) for _ in range(c[1])] for c in cases}
 for k, a in enumerate(sys.argv[1:]):
     out = os.path.join(ROOT, "gpurun_out", "libsv%d.so" % k)
@@ -25,10 +26,10 @@ for k, a in enumerate(sys.argv[1:]):
         ts = []
         for _ in range(5):
             try:
-                eng.score_batch(seqs[(L, R)], E.NEED_PF)
+                eng.score_batch(seqs[(L, R)], E.NEED_PF if WHAT == "pf" else E.NEED_MFE)
             except Exception:
                 pass
-            ts.append(eng.last_timing()["pf"])
+            ts.append(eng.last_timing()[WHAT])
         res.append("L=%d R=%d %.3f ms" % (L, R, min(ts[1:])))
         eng.close()
     print("%-28s %s" % (a or "(default)", " | ".join(res)), flush=True)
