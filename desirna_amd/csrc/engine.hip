@@ -97,6 +97,7 @@ struct drna_engine {
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
   int32_t* d_srec = nullptr;      // MFE strips: exchange records and list counts, srec_stride int32 per sequence
   long long srec_stride = 0;
+  long long* d_sclk = nullptr;    // DRNA_STRIP_DEBUG=1: start / end clocks of the MFE strip workgroups of the last launch
   int* d_sdbg = nullptr;          // DRNA_STRIP_DEBUG=1: [2][max_R][8] words written by a strip whose wait failed
   std::string err;
 };
@@ -143,13 +144,14 @@ static int strip_flags(drna_engine* e, bool mfe) {
     HIP_TRY(hipDeviceSynchronize());      // the memset runs on the null stream, the kernels on non-blocking streams of their own
     e->strip_epoch = 0;
     if (getenv("DRNA_STRIP_DEBUG")) {
+      HIP_TRY(hipMalloc((void**)&e->d_sclk, (size_t)e->max_R * STRIP_MAXS * 2 * sizeof(long long)));
       HIP_TRY(hipMalloc((void**)&e->d_sdbg, (size_t)2 * e->max_R * 8 * sizeof(int)));
       HIP_TRY(hipMemset(e->d_sdbg, 0, (size_t)2 * e->max_R * 8 * sizeof(int)));
       HIP_TRY(hipDeviceSynchronize());
     }
   }
   if (mfe && !e->d_srec) {
-    const int smax = strip_count(std::min(e->max_L, STRIP_NMAX), STRIP_WMAX);
+    const int smax = std::min(STRIP_MAXS, strip_count(std::min(e->max_L, STRIP_NMAX), STRIP_WMAX) + 1);
     e->srec_stride = (long long)std::max(smax, 2) * (e->max_L + 2) * MSTRIP_REC;
     HIP_TRY(hipMalloc((void**)&e->d_srec, (size_t)e->srec_stride * e->max_R * sizeof(int32_t)));
   }
@@ -168,7 +170,7 @@ static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, i
   lk.nseq = nseq; lk.S = S; lk.idx = idx;
   lk.dbg = e->d_sdbg ? e->d_sdbg + (size_t)first_slot * 8 : nullptr;
   const int groups = (nseq + 7) / 8;
-  hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * S), dim3(1024), 0, st, a, lk);
+  hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * (S + STRIP_PAD)), dim3(1024), 0, st, a, lk);
 }
 
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
@@ -183,7 +185,8 @@ static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S,
     lk.base = next_strip_epoch(e);
     lk.nseq = nseq; lk.S = S; lk.idx = idx;
     lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
-    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * S), dim3(1024), 0, st, a, lk, xr, round);
+    lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
+    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + STRIP_PAD)), dim3(1024), 0, st, a, lk, xr, round);
     hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round);
   }
 }
@@ -267,7 +270,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
                   e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss,
-                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg};
+                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg, e->d_sclk};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -290,6 +293,15 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
+}
+
+// diagnostics (DRNA_STRIP_DEBUG=1): start / end wall clocks (100 MHz ticks) of the MFE strip workgroups of the last launch,
+// out[slot][strip][2]; returns the number of slots copied (0 without the debug buffers)
+extern "C" int drna_debug_strip_clocks(drna_engine* e, long long* out, int nslots) {
+  if (!e || !e->d_sclk || !out) return 0;
+  const int m = std::min(nslots, e->max_R);
+  if (hipMemcpy(out, e->d_sclk, (size_t)m * STRIP_MAXS * 2 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return m;
 }
 
 extern "C" const char* drna_last_error(const drna_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }

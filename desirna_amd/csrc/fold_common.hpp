@@ -250,6 +250,14 @@ __device__ __forceinline__ int rtype_of(int t) {
 #ifndef STRIP_DIAG
 #define STRIP_DIAG 0     // diagnostic builds only (timing; results wrong): 1 plain table stores, 2 plain multiloop loads, 4 no waits / records in,
 #endif                   // 8 barrier without store drain, 16 no record exports
+#ifndef DRNA_STRIP_PAD
+#define DRNA_STRIP_PAD 1
+#endif
+// Empty blocks per sequence behind its strips.  Workgroups of an XCD are dealt to its shader engines in turn and start in order:
+// with four strips per sequence and no padding, strip s of EVERY sequence lands on engine s, the long-lived last strips queue
+// behind each other on a quarter of the CUs and the rest idles (measured: tools/strip_clocks.py).  One empty block per
+// sequence rotates the assignment.
+constexpr int STRIP_PAD = DRNA_STRIP_PAD;
 constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
 constexpr int STRIP_REC = 88;                         // doubles per exchange record
 constexpr int STRIP_MAXS = 8;                         // strips per sequence at most
@@ -263,9 +271,31 @@ struct StripLink {
   int S = 0;                 // strips per sequence
   const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null
   int* dbg = nullptr;        // diagnostics: 8 words per sequence slot, written by a strip whose wait failed
+  long long* clk = nullptr;  // diagnostics: start / end wall clock (100 MHz) of every strip workgroup, [slot][STRIP_MAXS][2]
 };
-__host__ __device__ inline int strip_count(int n, int wmax) { return (n + wmax - 1) / wmax; }
-__host__ __device__ inline int strip_width(int n, int S) { return (n + S - 1) / S; }
+// Layout of the strips of an n-nt sequence.  The LAST strip (columns from 1: it lives through all n diagonals, and its
+// multiloop sums are the longest) is narrower than the others: DRNA_STRIP_SKEW percent of the mean width, at least 32 columns
+// (a halo reaches 31); the strips above it share the rest evenly, at most `wmax` columns each.
+#ifndef DRNA_STRIP_SKEW
+#define DRNA_STRIP_SKEW 100
+#endif
+__host__ __device__ inline int strip_last_width(int n, int S) {
+  int w = (n * DRNA_STRIP_SKEW + 50 * S) / (100 * S);
+  return w < 32 ? 32 : w;
+}
+__host__ __device__ inline int strip_upper_width(int n, int S) { return S > 1 ? (n - strip_last_width(n, S) + S - 2) / (S - 1) : 0; }
+__host__ __device__ inline int strip_count(int n, int wmax) {
+  for (int S = 2; S <= STRIP_MAXS; S++)
+    if (strip_last_width(n, S) <= wmax && strip_upper_width(n, S) <= wmax && strip_last_width(n, S) < n) return S;
+  return STRIP_MAXS + 1;
+}
+// columns [c0, c1] of strip s (0 = highest columns); c0 > n: the strip is empty
+__host__ __device__ inline void strip_bounds(int n, int S, int s, int& c0, int& c1) {
+  const int t = S - 1 - s, wl = strip_last_width(n, S), wu = strip_upper_width(n, S);
+  if (t == 0) { c0 = 1; c1 = wl < n ? wl : n; return; }
+  c0 = wl + (t - 1) * wu + 1;
+  c1 = c0 + wu - 1 < n ? c0 + wu - 1 : n;
+}
 
 struct StripRec {              // MFE strips: exchange records and list counts live in a buffer of their own
   int32_t* rec = nullptr;

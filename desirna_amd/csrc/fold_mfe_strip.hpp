@@ -104,11 +104,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   const int ninio = T.ninio, max_ninio = T.max_ninio, MLbase = T.MLbase, MLclosing = T.MLclosing,
             MLintern = T.MLintern, TermAU = T.TermAU;
   const int S = lk.S;
-  const int wfull = strip_width(n, S);
-  const int t_ = S - 1 - s;
-  const int c0 = t_ * wfull + 1;
+  int c0, c1;
+  strip_bounds(n, S, s, c0, c1);
   if (c0 > n) return;
-  const int c1 = min(n, (t_ + 1) * wfull);
   const int wid = c1 - c0 + 1, n_loc = n - c0 + 1;
   const bool has_up = c1 < n, has_down = c0 > 1, last = !has_down;
   const int n_loc_up = n_loc - wid;
@@ -129,6 +127,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 
   // later rounds run only for sequences whose previous round found a pair (state word 1, written by the traceback kernel)
   if (round > 0 && Wc[0] != 1) return;
+#ifndef DRNA_EMU
+  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2] = wall_clock64();
+#endif
 
   // ---- prologue: tables
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
@@ -474,6 +475,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     }
     return;
   }
+#ifndef DRNA_EMU
+  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2 + 1] = wall_clock64();
+#endif
   if (has_down) {
     if (tid == 0) st_agent(my_flag, lk.base + STRIP_DONE);
     return;
@@ -504,10 +508,10 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 template <int NT>
 __global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
   __shared__ MfeStripSmem<NT> sm;
-  const int b = blockIdx.x, per = 8 * lk.S;
+  const int b = blockIdx.x, per = 8 * (lk.S + STRIP_PAD);
   const int grp = b / per, x = b - grp * per;
   const int q = grp * 8 + (x & 7), s = x >> 3;
-  if (q >= lk.nseq) return;
+  if (q >= lk.nseq || s >= lk.S) return;          // (padding blocks: see STRIP_PAD)
   mfe_strip_body<NT>(sm, A, lk, xr, q, s, round);
 }
 

@@ -107,11 +107,9 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
   // strips of this sequence: a launch is made for S strips; shorter sequences of a ragged batch may need fewer
   const int S = lk.S;
-  const int wfull = strip_width(n, S);
-  const int t_ = S - 1 - s;
-  const int c0 = t_ * wfull + 1;
-  if (c0 > n) return;                                     // (cannot happen for n > (S-1) * S; kept for safety)
-  const int c1 = min(n, (t_ + 1) * wfull);
+  int c0, c1;
+  strip_bounds(n, S, s, c0, c1);
+  if (c0 > n) return;
   const int wid = c1 - c0 + 1, n_loc = n - c0 + 1;
   const bool has_up = c1 < n, has_down = c0 > 1;
   const int n_loc_up = n_loc - wid;                       // suffix length of the strip above
@@ -588,10 +586,10 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
 template <int NT>
 __global__ __launch_bounds__(NT) void pf_strip_kernel(PfArgs A, StripLink lk) {
   __shared__ PfStripSmem<NT> sm;
-  const int b = blockIdx.x, per = 8 * lk.S;
+  const int b = blockIdx.x, per = 8 * (lk.S + STRIP_PAD);
   const int grp = b / per, x = b - grp * per;
   const int q = grp * 8 + (x & 7), s = x >> 3;
-  if (q >= lk.nseq) return;
+  if (q >= lk.nseq || s >= lk.S) return;          // (padding blocks: see STRIP_PAD)
   pf_strip_body<NT>(sm, A, lk, q, s);
 }
 

@@ -25,7 +25,7 @@ EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
            "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
-           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums")
+           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums", "drna_debug_strip_clocks")
 
 RNG_WORDS = 625        # DRNA_RNG_WORDS: uint32 words of one replica's MT19937 stream
 

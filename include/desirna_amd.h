@@ -178,6 +178,10 @@ int drna_last_edef_timing(const drna_engine *e, float out[2]);
  */
 int drna_set_option(drna_engine *e, const char *name, int value);
 
+/* diagnostics (engine created with DRNA_STRIP_DEBUG=1 in the environment): start / end wall clocks (100 MHz ticks) of the MFE
+ * strip workgroups of the last launch, out[slot][8][2]; returns the number of sequence slots copied (0 without the buffers) */
+int drna_debug_strip_clocks(drna_engine *e, long long *out, int nslots);
+
 /* engine facts: out[0]=device, out[1]=max_R, out[2]=max_L, out[3]=threads per workgroup,
  * out[4]=compute units, out[5]=bytes of device workspace */
 int drna_info(const drna_engine *e, int64_t out[6]);

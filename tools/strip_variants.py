@@ -14,7 +14,7 @@ for k, a in enumerate(sys.argv[1:]):
 for p in procs:
     p.wait()
 rng = np.random.default_rng(11)
-cases = [(400, 64), (400, 128), (400, 256)]
+cases = [(400, 64), (400, 128), (400, 256), (300, 128)]
 WHAT = os.environ.get("WHAT", "pf")
 seqs = {c: ["".join(rng.choice(list("ACGU"), c[0])) for _ in range(c[1])] for c in cases}
 for k, a in enumerate(sys.argv[1:]):
