@@ -17,6 +17,9 @@
 namespace drna {
 
 constexpr int MSTRIP_REC = 96;        // int32 per exchange record
+#ifndef MSTRIP_SKIP
+#define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize
+#endif
 
 template <int NT>
 struct MfeStripSmem {
@@ -79,7 +82,7 @@ __device__ __forceinline__ void mstrip_tower(SM& sm, int (&G)[GSLOTS], int d, in
       G[qx] = mine ? v : G[qx];
     }
   }
-  const int accG = mfe_tower_step(sm, G, par, i * 4, my_g, SM::NG, lane);
+  const int accG = (MSTRIP_SKIP & 4) ? INF_DEV : mfe_tower_step(sm, G, par, i * 4, my_g, SM::NG, lane);
   if (live) atomicMin(&sm.accG[par][phys], accG);
   if (!(STRIP_DIAG & 16) && has_down && live && iraw == 1) {
     int32_t* rec = rec_out + (long long)d * MSTRIP_REC + 64 + my_g * GSLOTS;
@@ -260,7 +263,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     const int kssh = d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0;
     const int KS = 1 << kssh, KG = 4 << kssh;
     const int astep = 4 * KG * ld, cstep = 4 * KG * (ld - 1);
-    const int nK = ((ncell + 63) >> 6) << kssh, nE = (pcnt + 3) >> 2;
+    const int nK = (MSTRIP_SKIP & 1) ? 0 : ((ncell + 63) >> 6) << kssh, nE = (MSTRIP_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
     auto pop = [&]() -> int {
       if (decltype(with_k)::value) {
@@ -373,7 +376,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
         const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
         const int i = ((tid - sh - 1) & (P - 1)) + 1;
         const int dm1v = as_vector(d - 1);
-        if (i <= ncell) {
+        if (!(MSTRIP_SKIP & 8) && i <= ncell) {
           const int aG = sm.accG[par][tid], aI = sm.accI[par][tid], aK = sm.accK[par][tid];
           sm.accG[par][tid] = INF; sm.accI[par][tid] = INF; sm.accK[par][tid] = INF;
           const int j = i + d;
