@@ -325,6 +325,12 @@ template <typename T> __device__ __forceinline__ void strip_store(T* p, T v) {
   st_agent(p, v);
 #endif
 }
+// 8-byte buffer load that bypasses this CU's L1 (sc1): for cells another workgroup stored
+template <typename RS>
+__device__ __forceinline__ double buf_load_f64_aux(RS rsrc, int voff, int soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
 template <typename RS>
 __device__ __forceinline__ f64x2 buf_load_f64x2_sc1(RS rsrc, int voff, int soff) {
   const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);     // aux 16 = sc1: bypasses this CU's L1

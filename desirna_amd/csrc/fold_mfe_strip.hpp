@@ -17,6 +17,14 @@
 namespace drna {
 
 constexpr int MSTRIP_REC = 96;        // int32 per exchange record
+#ifdef MSTRIP_STAMPS
+#define MST(k) do { const long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
+#else
+#define MST(k) do { } while (0)
+#endif
+#ifndef MSTRIP_LEAD
+#define MSTRIP_LEAD 0
+#endif
 #ifndef MSTRIP_SKIP
 #define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize
 #endif
@@ -62,6 +70,30 @@ template <typename RSRC>
 __device__ __forceinline__ i32x4 buf_load_i32x4_sc1(RSRC rsrc, int voff, int soff) {
   const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);
   return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+
+// exterior column j: f5[j] = min(f5[j-1], min_i f5[i-1] + EXT[j][i]); one wave.  The column's cells come from every strip: sc1
+// loads, all of them issued before the first is used (a chain of dependent round trips here was the whole step's floor)
+template <class SM, typename RSRC>
+__device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j, int lane) {
+  constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+  const int cnt = j - TURN - 1;                       // cells i = 1 .. cnt
+  const int nch = (cnt + WAVE - 1) >> 6;
+  int fx[NFX];
+#pragma unroll
+  for (int c = 0; c < NFX; c++) {
+    fx[c] = INF_DEV;
+    if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+  }
+  int m = INF_DEV;
+#pragma unroll
+  for (int c = 0; c < NFX; c++) {
+    const int i = lane + 1 + c * WAVE;
+    if (c < nch && i <= cnt && fx[c] < INF_DEV / 2) m = min(m, sm.f5[i - 1] + fx[c]);
+  }
+  m = wave_min_i32(m);
+  const int prev = sm.f5[j - 1];
+  sm.f5[j] = prev < m ? prev : m;
 }
 
 // one diagonal step of a tower wave: import of the tower that enters the strip, the recurrence, export of the one that leaves
@@ -241,6 +273,14 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   if (wave == w_svcA) {
     const int d = TURN + 1;
     if (d < n_loc) mfe_prepare_tower_tab(sm, d, lane, ninio, max_ninio);
+#if MSTRIP_LEAD > 0
+    // let the strip above get MSTRIP_LEAD diagonals ahead before this one starts: both run at the same pace, so the lead stays,
+    // its flags are then always there when asked for and its records can be requested a step early (see service_a)
+    if (!(STRIP_DIAG & 4) && has_up && n_loc_up - 1 > TURN) {
+      int seen = 0;
+      (void)strip_wait(up_flag, lk.base, min(TURN + 1 + MSTRIP_LEAD, n_loc_up - 1), seen);
+    }
+#endif
   }
   if (wave == w_svcB) {
     const int d = TURN + 1;
@@ -253,6 +293,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   __syncthreads();
 
   const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)(tab * 4), 0x00020000);
+  const auto rsE = __builtin_amdgcn_make_buffer_rsrc((void*)EXT, (short)0, (int)(tab * 4), 0x00020000);
   const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
 
   // floating work items of diagonal d: multiloop splits from L2 (64 cells x 4 split-point groups per item, four adjacent cells
@@ -316,57 +357,97 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     }
   };
 
-  // ---- service jobs of step k
+  // ---- service jobs of step k.  What they read was stored write-through by other workgroups (or long ago by the prologue):
+  // it comes from beyond the L2, ~1.5 us a trip -- with the loads inside the step the service waves WERE the floor of a step
+  // (3.4 k of its 4.2 k cycles, tools/strip_stamps.py).  So every load is requested one step AHEAD and consumed from registers
+  // at the top of the next step; the registers ride across the items and the barrier.
   // A: the record of diagonal k-1 of the strip above (ring halo, fML / decomposition minimum of its first column, the minima of
-  //    the tower that enters at diagonal k+1); tower table of diagonal k+1
+  //    the tower that enters at diagonal k+1).  It is requested as soon as a flag value READ EARLIER covers it (the flag itself
+  //    is re-read every step, one step ahead as well); only when the strip above is less than two diagonals ahead does the
+  //    wave wait (bounded) and load inside the step.  Tower table of diagonal k+1.
+  int sa_w0 = 0, sa_g0 = 0, sa_f = lk.base;
+  bool sa_pend = false;
+  auto sa_request = [&](const int dd) {                               // record of diagonal dd -> registers
+    const int32_t* rec = rec_in + (long long)dd * MSTRIP_REC;
+    sa_w0 = ld_agent(rec + lane);                                     // lanes 0..31 ring words, 32..63 c + mismatchI words
+    sa_g0 = ld_agent(rec + 64 + (lane & 31));                         // tower minima (30), fML, decomposition minimum
+  };
   auto service_a = [&](const int k) {
-    if (!(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1) {
-      int seen = 0;
-      if (!strip_wait(up_flag, lk.base, k - 1, seen)) {
+    const bool need = !(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1;
+    if (need) {
+      if (!sa_pend) {
+        int seen = sa_f;
+        if (!flag_ge(sa_f, lk.base + k - 1)) (void)strip_wait(up_flag, lk.base, k - 1, seen);
+        sa_f = seen;
+        if (flag_ge(sa_f, lk.base + k - 1) && sa_f != lk.base + STRIP_FAIL) { sa_request(k - 1); sa_pend = true; }
+      }
+      if (!sa_pend) {
         sm.sync_fail[k & 1] = 1;
-        if (lane == 0 && lk.dbg) { int* g = lk.dbg + q * 8; g[0] = s + 1; g[1] = k; g[2] = seen; g[3] = lk.base; g[4] = (int)blockIdx.x; g[5] = n; }
-      }
-      else {
+        if (lane == 0 && lk.dbg) { int* g = lk.dbg + q * 8; g[0] = s + 1; g[1] = k; g[2] = sa_f; g[3] = lk.base; g[4] = (int)blockIdx.x; g[5] = n; }
+      } else {
         const int dd = k - 1;
-        const int32_t* rec = rec_in + (long long)dd * MSTRIP_REC;
-        const int w0 = ld_agent(rec + lane);                            // lanes 0..31 ring words, 32..63 c + mismatchI words
-        const int g0 = lane < 32 ? ld_agent(rec + 64 + lane) : 0;       // tower minima (30), fML, decomposition minimum
-        if (lane < 32) sm.wring[(dd & 31) * RS + wid + 1 + lane] = w0;
-        else sm.ciring[(dd & 31) * RS + wid + 1 + lane - 32] = w0;
-        if (lane < NG * GSLOTS) sm.gimp[(k + 1) & 1][lane / GSLOTS][lane % GSLOTS] = g0;
-        if (lane == 30) sm.fmlrow[dd & 1][wid + 1] = g0;
-        if (lane == 31) sm.dml[(dd & 3) * RS + wid + 1] = g0;
+        if (lane < 32) sm.wring[(dd & 31) * RS + wid + 1 + lane] = sa_w0;
+        else sm.ciring[(dd & 31) * RS + wid + 1 + lane - 32] = sa_w0;
+        if (lane < NG * GSLOTS) sm.gimp[(k + 1) & 1][lane / GSLOTS][lane % GSLOTS] = sa_g0;
+        if (lane == 30) sm.fmlrow[dd & 1][wid + 1] = sa_g0;
+        if (lane == 31) sm.dml[(dd & 3) * RS + wid + 1] = sa_g0;
       }
+    }
+    sa_pend = false;
+    // one step ahead: the record of diagonal k, if the flag as last seen covers it; and the flag again
+    const bool next = !(STRIP_DIAG & 4) && has_up && k > TURN && k <= n_loc_up - 1;
+    if (next) {
+      if (flag_ge(sa_f, lk.base + k) && sa_f != lk.base + STRIP_FAIL) { sa_request(k); sa_pend = true; }
+      sa_f = __builtin_amdgcn_readfirstlane(ld_agent(up_flag));
     }
     if (k + 1 < n_loc) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
   };
-  // B: pairable list of diagonal k+1; exterior column j = k-3 (last strip)
-  auto service_b = [&](const int k) {
+  // B: pairable list of diagonal k+1 (entries beyond the count are never read, so the rows do not wait for it); exterior
+  //    column j = k-3 (last strip).  Both requested one step ahead: lp_* / fx_*.
+  constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+  int lp_cnt = 0, lp_p0 = 0, lp_p1 = 0, lp_x0 = 0, lp_x1 = 0, fx[NFX];
+  auto sb_request = [&](const int k) {                                // for step k: list of diagonal k+1, column k-3
     if (k + 1 < n_loc) {
-      const int dn = k + 1;
-      const int cnt = PLC[dn * STRIP_MAXS + s];
-      const int32_t* row = PL + dn * ld + c0 - 1;
-      const int32_t* rowx = PLX + dn * ld + c0 - 1;
-      const int p0 = lane < cnt ? row[lane] : 0, p1 = lane + WAVE < cnt ? row[lane + WAVE] : 0;
-      const int x0 = lane < cnt ? rowx[lane] : 0, x1 = lane + WAVE < cnt ? rowx[lane + WAVE] : 0;
-      sm.plist[dn & 1][lane] = p0; sm.xe[dn & 1][lane] = x0;
-      if (lane + WAVE < SM::NL) { sm.plist[dn & 1][lane + WAVE] = p1; sm.xe[dn & 1][lane + WAVE] = x1; }
-      if (lane == 0) { sm.pcnt[dn & 1] = cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
+      const int32_t* row = PL + (k + 1) * ld + c0 - 1;
+      const int32_t* rowx = PLX + (k + 1) * ld + c0 - 1;
+      lp_cnt = PLC[(k + 1) * STRIP_MAXS + s];
+      lp_p0 = row[lane]; lp_p1 = row[min(lane + WAVE, wid)];
+      lp_x0 = rowx[lane]; lp_x1 = rowx[min(lane + WAVE, wid)];
     }
-    if (last && k - 3 >= TURN + 2) {
-      const int j = k - 3;
+    const int j = k - 3, fcnt = j - TURN - 1;
+    const int nch = (last && j >= TURN + 2) ? (fcnt + WAVE - 1) >> 6 : 0;
+#pragma unroll
+    for (int c = 0; c < NFX; c++) {
+      fx[c] = INF;
+      if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+    }
+  };
+  if (wave == w_svcB) sb_request(TURN + 1);
+  auto service_b = [&](const int k) {
+    const int dn = k + 1, j = k - 3, fcnt = j - TURN - 1;
+    if (k + 1 < n_loc) {
+      sm.plist[dn & 1][lane] = lp_p0; sm.xe[dn & 1][lane] = lp_x0;
+      if (lane + WAVE < SM::NL) { sm.plist[dn & 1][lane + WAVE] = lp_p1; sm.xe[dn & 1][lane + WAVE] = lp_x1; }
+      if (lane == 0) { sm.pcnt[dn & 1] = lp_cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
+    }
+    if (last && j >= TURN + 2) {
       int m = INF;
-      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
-        const int x = ld_agent(&EXT[j * ld + i]);
-        if (x < HALF) m = min(m, sm.f5[i - 1] + x);
+#pragma unroll
+      for (int c = 0; c < NFX; c++) {
+        const int i = lane + 1 + c * WAVE;
+        if (c * WAVE < fcnt && i <= fcnt && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
       }
       m = wave_min_i32(m);
       const int prev = sm.f5[j - 1];
       sm.f5[j] = prev < m ? prev : m;
     }
+    sb_request(k + 1);              // column k-2: its cells (diagonals <= k-3) were stored in step k-2 and drained by its barrier
   };
 
   bool failed = false;
+#ifdef MSTRIP_STAMPS
+  long long st_acc[4] = {0, 0, 0, 0}, st_last = clock64();
+#endif
   if (fin) {
     // ================= finalize waves: diagonal d = k-1 at step k
     for (int k = TURN + 1; k <= n_loc; k++) {
@@ -428,23 +509,31 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
         }
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
+      MST(0);
       if (k < n_loc) run_items(k, std::true_type{});
+      MST(1);
       STRIP_BARRIER();
+      MST(2);
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }
   } else if (NSVC && wave < NFIN + NSVC) {
     // ================= service waves
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (wave == w_svcA) service_a(k); else service_b(k);
+      MST(0);
       if (k < n_loc) run_items(k, std::true_type{});
+      MST(1);
       STRIP_BARRIER();
+      MST(2);
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }
   } else if (!pinned) {
     // ================= floating waves: items only
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (k < n_loc) run_items(k, std::true_type{});
+      MST(1);
       STRIP_BARRIER();
+      MST(2);
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }
   } else {
@@ -457,20 +546,30 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     for (int k = TURN + 1; k <= n_loc; k += 2) {
       if (k < n_loc) {
         mstrip_tower(sm, GE, k, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        MST(0);
         run_items(k, std::false_type{});
+        MST(1);
       }
       STRIP_BARRIER();
+      MST(2);
       if (sm.sync_fail[k & 1]) { failed = true; break; }
       if (k + 1 > n_loc) break;
       if (k + 1 < n_loc) {
         mstrip_tower(sm, GO, k + 1, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        MST(0);
         run_items(k + 1, std::false_type{});
+        MST(1);
       }
       STRIP_BARRIER();
+      MST(2);
       if (sm.sync_fail[(k + 1) & 1]) { failed = true; break; }
     }
   }
 
+#ifdef MSTRIP_STAMPS
+  if (lk.clk && q == 0 && last && lane == 0)
+    for (int k = 0; k < 4; k++) lk.clk[16 + wave * 4 + k] = st_acc[k];
+#endif
   if (failed) {
     if (tid == 0) {
       if (has_down) st_agent(my_flag, lk.base + STRIP_FAIL);
@@ -487,16 +586,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   }
   // last strip: the remaining exterior columns; f5 and the state word go to the traceback kernel
   if (wave == 0) {
-    for (int j = max(TURN + 2, n - 2); j <= n; j++) {
-      int m = INF;
-      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
-        const int x = ld_agent(&EXT[j * ld + i]);
-        if (x < HALF) m = min(m, sm.f5[i - 1] + x);
-      }
-      m = wave_min_i32(m);
-      const int prev = sm.f5[j - 1];
-      sm.f5[j] = prev < m ? prev : m;
-    }
+    for (int j = max(TURN + 2, n - 2); j <= n; j++) mstrip_f5_column(sm, rsE, ld, j, lane);
   }
   __syncthreads();
   for (int k = tid; k <= n; k += NT) Wc[ld + k] = sm.f5[k];

@@ -239,6 +239,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   __syncthreads();
 
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)QEXT, (short)0, (int)(tab * 8), 0x00020000);
 
   // floating work items of diagonal d (see pf_lds_kernel): multiloop sums from L2 (the qm1 operand may be another strip's: sc1),
   // bulge / 1xn shapes, fixed small shapes.  Output slots are physical tower lanes (i_loc + d/2) mod P.
@@ -404,21 +405,44 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     if (k + 1 < n_loc) pf_prepare_tables(sm, k + 1, lane);
   };
   // B: pairable list of diagonal k+1; exterior column j = k-3 (last strip)
+  // (every load of the job is issued before the first is used, the column's cells first; the list of diagonal k+2 -- rows
+  // written by the prologue long ago, i.e. from HBM -- is requested one step ahead and stays in flight behind them)
+  int lp_cnt = 0, lp_p0 = 0, lp_p1 = 0;
+  if (wave == w_svcB && TURN + 2 < n_loc) {
+    const int32_t* row = PL + (TURN + 2) * ld + c0 - 1;
+    lp_cnt = PLC[(TURN + 2) * STRIP_MAXS + s];
+    lp_p0 = row[lane]; lp_p1 = row[min(lane + WAVE, wid)];
+  }
   auto service_b = [&](const int k) {
-    if (k + 1 < n_loc) {
-      const int dn = k + 1;
-      const int cnt = PLC[dn * STRIP_MAXS + s];
-      const int32_t* row = PL + dn * ld + c0 - 1;
-      const int p0 = lane < cnt ? row[lane] : 0, p1 = lane + WAVE < cnt ? row[lane + WAVE] : 0;
+    constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+    const bool do_list = k + 1 < n_loc, do_q5 = last && k - 3 >= TURN + 2;
+    const int dn = k + 1, j = k - 3;
+    const int cnt = lp_cnt, p0 = lp_p0, p1 = lp_p1;
+    const int fcnt = j - TURN - 1, nch = do_q5 ? (fcnt + WAVE - 1) >> 6 : 0;
+    double fx[NFX];
+#pragma unroll
+    for (int c = 0; c < NFX; c++) {
+      fx[c] = 0.0;
+      if (c < nch) fx[c] = buf_load_f64_aux(rsX, (j * ld + min(lane + 1 + c * WAVE, fcnt)) * 8, 0);
+    }
+    if (k + 2 < n_loc) {
+      const int32_t* row = PL + (k + 2) * ld + c0 - 1;
+      lp_cnt = PLC[(k + 2) * STRIP_MAXS + s];
+      lp_p0 = row[lane]; lp_p1 = row[min(lane + WAVE, wid)];
+    }
+    if (do_list) {
       int* dst = sm.plist[dn & 1];
       dst[lane] = p0;
       if (lane + WAVE < SM::NL) dst[lane + WAVE] = p1;
       if (lane == 0) { sm.pcnt[dn & 1] = cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
     }
-    if (last && k - 3 >= TURN + 2) {
-      const int j = k - 3;
+    if (do_q5) {
       double sacc = 0.0;
-      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) sacc += sm.q5[i - 1] * ld_agent(&QEXT[j * ld + i]);
+#pragma unroll
+      for (int c = 0; c < NFX; c++) {
+        const int i = lane + 1 + c * WAVE;
+        if (c < nch && i <= fcnt) sacc += sm.q5[i - 1] * fx[c];
+      }
       sacc = wave_sum_f64(sacc);
       sm.q5[j] = sm.q5[j - 1] * sc1 + sacc;
     }
