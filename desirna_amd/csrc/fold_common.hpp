@@ -90,6 +90,16 @@ __device__ __forceinline__ bool wait_flag_wave(const int* flag, int target) {
   return false;
 }
 
+// all lanes of the wave have executed their LDS operations up to here (wave-private staging through LDS)
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef DRNA_EMU
+  pthread_barrier_wait(&emu_g->waves[threadIdx.x >> 6].bar);
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#endif
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -29,6 +29,30 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize
 #endif
 
+#ifndef MSTRIP_FARK
+#define MSTRIP_FARK 0        // 1 = multiloop splits in blocked form (see far_blocks): correct, not yet faster; 0 = every split point per diagonal
+#endif
+// ---- blocked multiloop splits.  With k = i + tt + 1 the split minimum of cell (i, j) is min_k F[i, k-1] + F[k, j], k = i+5 .. j-4:
+// a (min,+) matrix product.  Cells are grouped in tiles of 16 columns i (anchored at the strip's first column) x 16 columns j
+// (anchored at multiples of 16); the part of the product over the 16-blocks of k that lie well inside -- k >= imax + lat + 17 and
+// k + 15 <= jmin - lat - 16 -- has operands that are final `lat` diagonals before the tile's first cell is due, so it is computed
+// there as dense 16 x 16 x 16 tile products (both operand tiles staged through LDS once: 1 load per 16 terms instead of 2 per
+// term) into an LDS slot of the tile; only the <= ~100 split points next to i and to j stay in the per-diagonal items.
+// lat differs by tile row (4 + 2 t) so that the tile rows of a strip have their turn at different steps.
+__host__ __device__ inline int far_lat(int t) { return 4 + 2 * (t & 7); }
+__host__ __device__ inline bool far_blocks(int c0, int c1, int t, int bj, int& bk_lo, int& bk_hi) {
+  const int imax = (c0 + 16 * t + 15 < c1 ? c0 + 16 * t + 15 : c1), lat = far_lat(t);
+  bk_lo = (imax + lat + 17 + 15) >> 4;
+  const int hi = 16 * bj - lat - 31;
+  bk_hi = hi >= 0 ? hi >> 4 : -1;
+  return bk_hi >= bk_lo;
+}
+#ifndef DRNA_FAR_CH
+#define DRNA_FAR_CH 4
+#endif
+constexpr int FAR_CH = DRNA_FAR_CH;          // k-blocks per far item
+constexpr int FAR_TAB = 128;       // far items per step at most
+
 template <int NT>
 struct MfeStripSmem {
   static constexpr int NW = NT / WAVE;
@@ -51,6 +75,10 @@ struct MfeStripSmem {
   int dml[4 * RS];               // decomposition minima of the last 4 diagonals
   int fmlrow[2][RS];             // fML of the last two diagonals
   int accG[2][P], accI[2][P], accK[2][P];
+  int dfar[P / 16][4][256];      // far part of the split minimum of a tile: [tile row][16-block of j & 3][16 x 16 cells]
+  int fstage[NW][16 * 17 + 256]; // per wave: the two operand tiles of a tile product
+  int far_tab[2][FAR_TAB];       // far items of the step: tile row | j-block << 4 | first k-block << 12 | k-blocks << 20
+  int far_cnt[2];
   int gimp[2][NG][GSLOTS + 2];   // minima of the tower that enters the strip, staged by the service wave
   int xtab[64 + 1024 + 128 + 128];
   int plist[2][NL];
@@ -85,11 +113,18 @@ __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j
     fx[c] = INF_DEV;
     if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
   }
+  int fv[NFX];
+#pragma unroll
+  for (int c = 0; c < NFX; c++) {
+    fv[c] = 0;
+    if (c < nch) fv[c] = sm.f5[min(lane + 1 + c * WAVE, cnt) - 1];
+  }
   int m = INF_DEV;
 #pragma unroll
   for (int c = 0; c < NFX; c++) {
     const int i = lane + 1 + c * WAVE;
-    if (c < nch && i <= cnt && fx[c] < INF_DEV / 2) m = min(m, sm.f5[i - 1] + fx[c]);
+    const int v = fv[c] + fx[c];
+    m = (c < nch && i <= cnt && fx[c] < INF_DEV / 2 && v < m) ? v : m;
   }
   m = wave_min_i32(m);
   const int prev = sm.f5[j - 1];
@@ -174,7 +209,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   }
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
-  if (tid == 0) { sm.flag = 0; sm.sync_fail[0] = 0; sm.sync_fail[1] = 0; }
+  if (tid == 0) { sm.flag = 0; sm.sync_fail[0] = 0; sm.sync_fail[1] = 0; sm.far_cnt[0] = 0; sm.far_cnt[1] = 0; }
   __syncthreads();
   // local sequence and pairing codes (4 = may not pair: positions paired in an earlier round, and both ends)
   const char* seq = A.seqs + so;
@@ -301,47 +336,66 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   auto run_items = [&](const int d, auto with_k) {
     const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
     const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
-    const int kssh = d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0;
+    const int tmax = d - TURN - 2;
+    // near split points: everything while no tile can have far blocks yet (d < 57), else the two ends of the range (the far
+    // blocks start <= 63 and end <= 80 split points from the ends; what a far block covers is masked per cell)
+    const bool two = MSTRIP_FARK && tmax > 63 + 16 && d - 80 > 64;
+    const int nterm = two ? 60 + (tmax - (d - 80) + 1) : tmax - TURN;
+    const int kssh = nterm > 96 ? 3 : nterm > 48 ? 2 : nterm > 24 ? 1 : 0;
     const int KS = 1 << kssh, KG = 4 << kssh;
-    const int astep = 4 * KG * ld, cstep = 4 * KG * (ld - 1);
     const int nK = (MSTRIP_SKIP & 1) ? 0 : ((ncell + 63) >> 6) << kssh, nE = (MSTRIP_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
-    const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
+    const int nF = (MSTRIP_FARK && !(MSTRIP_SKIP & 16)) ? __builtin_amdgcn_readfirstlane(sm.far_cnt[par]) : 0;
+    const int nKF = nK + nF;
+    const int nItems = __builtin_amdgcn_readfirstlane(nKF + nE);
     auto pop = [&]() -> int {
       if (decltype(with_k)::value) {
         const int it = queue_pop(&sm.qk[par], lane);
-        if (it < nK) return it;
+        if (it < nKF) return it;
       }
-      return nK + queue_pop(&sm.qe[par], lane);
+      return nKF + queue_pop(&sm.qe[par], lane);
     };
     for (int it = pop(); it < nItems; it = pop()) {
-      if (decltype(with_k)::value && it < nK) {
-        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
-        int i = ((it >> kssh) << 6) + 4 * cl + 1;
+      if (decltype(with_k)::value && it >= nF && it < nKF) {
+        const int itk = it - nF;
+        const int g = (itk & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+        int i = ((itk >> kssh) << 6) + 4 * cl + 1;
         const bool act = i <= ncell;
         i = act ? i : 1;
         const int ig = i + c0 - 1;
+        // per cell: split points tt <= lb or tt >= rb are near (all of them when the cell's tile has no far blocks)
+        int lb[4], rb[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          int bk_lo, bk_hi;
+          const bool hf = MSTRIP_FARK && far_blocks(c0, c1, (i - 1) >> 4, (ig + x + d) >> 4, bk_lo, bk_hi);
+          lb[x] = hf ? 16 * bk_lo - (ig + x) - 2 : 0x3fffffff;
+          rb[x] = hf ? 16 * bk_hi + 15 - (ig + x) : 0x3fffffff;
+        }
         int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
-        int tt = TURN + 1 + g;
-        const int tmax = d - TURN - 2;
-        int vA = (tt * ld + ig) * 4;                               // fML[i .. i+3, . + tt]
-        int vC = ((d - tt - 1) * ld + ig + tt + 1) * 4;            // fML[i+tt+1 .. , j ..]
-        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
-          const int vCl = vC - 3 * cstep;
-          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vCl, 3 * cstep);
-          const i32x4 a1 = buf_load_i32x4(rsF, vA, astep), c1v = buf_load_i32x4_sc1(rsF, vCl, 2 * cstep);
-          const i32x4 a2 = buf_load_i32x4(rsF, vA, 2 * astep), c2v = buf_load_i32x4_sc1(rsF, vCl, cstep);
-          const i32x4 a3 = buf_load_i32x4(rsF, vA, 3 * astep), c3v = buf_load_i32x4_sc1(rsF, vCl, 0);
-          vA += 4 * astep; vC -= 4 * cstep;
-          m0 = min(m0, min(min(a0.x + c0v.x, a1.x + c1v.x), min(a2.x + c2v.x, a3.x + c3v.x)));
-          m1 = min(m1, min(min(a0.y + c0v.y, a1.y + c1v.y), min(a2.y + c2v.y, a3.y + c3v.y)));
-          m2 = min(m2, min(min(a0.z + c0v.z, a1.z + c1v.z), min(a2.z + c2v.z, a3.z + c3v.z)));
-          m3 = min(m3, min(min(a0.w + c0v.w, a1.w + c1v.w), min(a2.w + c2v.w, a3.w + c3v.w)));
+        // the near split points as ONE index range v = 0 .. nv-1 (v < n1: tt = 4 + v; else tt = d - 80 + v - n1), dealt to the
+        // lanes' groups by v: four of them per trip, eight loads in flight
+        const int n1 = two ? 60 : tmax - TURN, r0 = two ? d - 80 : 0, nv = two ? 60 + (tmax - (d - 80) + 1) : n1;
+        auto tt_of = [&](const int v) { return v < n1 ? TURN + 1 + v : r0 + (v - n1); };
+#define NEARV(x, tq) ((tq) <= lb[x] || (tq) >= rb[x])
+        for (int v = g; v < nv; v += 4 * KG) {
+          i32x4 a[4], c[4];
+          int tq[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int vv = v + u * KG;
+            tq[u] = vv < nv ? tt_of(vv) : -1;
+            const int tl = tq[u] < 0 ? TURN + 1 : tq[u];
+            a[u] = buf_load_i32x4(rsF, (tl * ld + ig) * 4, 0);
+            c[u] = buf_load_i32x4_sc1(rsF, ((d - tl - 1) * ld + ig + tl + 1) * 4, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool on = tq[u] >= 0;
+            m0 = min(m0, on && NEARV(0, tq[u]) ? a[u].x + c[u].x : INF); m1 = min(m1, on && NEARV(1, tq[u]) ? a[u].y + c[u].y : INF);
+            m2 = min(m2, on && NEARV(2, tq[u]) ? a[u].z + c[u].z : INF); m3 = min(m3, on && NEARV(3, tq[u]) ? a[u].w + c[u].w : INF);
+          }
         }
-        for (; tt <= tmax; tt += KG) {
-          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vC, 0);
-          m0 = min(m0, a0.x + c0v.x); m1 = min(m1, a0.y + c0v.y); m2 = min(m2, a0.z + c0v.z); m3 = min(m3, a0.w + c0v.w);
-          vA += astep; vC -= cstep;
-        }
+#undef NEARV
         // the four 16-lane rows hold different split points of the same cells
         m0 = min(m0, __shfl_xor(m0, 16)); m1 = min(m1, __shfl_xor(m1, 16)); m2 = min(m2, __shfl_xor(m2, 16)); m3 = min(m3, __shfl_xor(m3, 16));
         m0 = min(m0, __shfl_xor(m0, 32)); m1 = min(m1, __shfl_xor(m1, 32)); m2 = min(m2, __shfl_xor(m2, 32)); m3 = min(m3, __shfl_xor(m3, 32));
@@ -351,8 +405,57 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           if (i + 2 <= ncell && m2 < HALF) atomicMin(&sm.accK[par][(i + 2 + sh) & (P - 1)], m2);
           if (i + 3 <= ncell && m3 < HALF) atomicMin(&sm.accK[par][(i + 3 + sh) & (P - 1)], m3);
         }
+      } else if (decltype(with_k)::value && it < nF) {
+        // ---- far item (first in the queue: its loads come from beyond the L2): nb tile products of tile (t, bj), k-blocks b0 ..: lane (r, q) = row r of the tile, columns 4q .. 4q+3
+        const int e = sm.far_tab[par][it];
+        const int t = e & 15, bj = (e >> 4) & 255, b0 = (e >> 12) & 255, nb = (e >> 20) & 15;
+        const int r = lane & 15, qq = lane >> 4;
+        const int imin = c0 + 16 * t, jmin = 16 * bj;
+        const int w = __builtin_amdgcn_readfirstlane(wave_id());
+        int* As = sm.fstage[w];
+        int* Cs = As + 16 * 17;
+        int acc0 = INF, acc1 = INF, acc2 = INF, acc3 = INF;
+        // every operand of the item's (up to FAR_CH) products is requested first: one trip beyond the L2 for all of them
+        int av[FAR_CH][4], cv[FAR_CH][4];
+#pragma unroll
+        for (int b = 0; b < FAR_CH; b++) {
+          const int kmin = 16 * (b0 + b);
+          // A[r][c] = F[imin + r, kmin + c - 1] (row = diagonal kmin + c - 1 - i of the strip's own cells);
+          // C[r][c] = F[kmin + r, jmin + c] (any strip above: sc1)
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const int c = 4 * qq + x;
+            const int ia = imin + r, ka = kmin + c;
+            const int kc = kmin + r, jc = jmin + c;
+            av[b][x] = INF; cv[b][x] = INF;
+            if (b < nb) {
+              if (ia <= c1) av[b][x] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, ((ka - 1 - ia) * ld + ia) * 4, 0, 0);
+              if (jc <= n) cv[b][x] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, ((jc - kc) * ld + kc) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+            }
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < FAR_CH; b++) {
+          if (b < nb) {
+            wave_lds_sync();                       // (the previous product's reads are done)
+#pragma unroll
+            for (int x = 0; x < 4; x++) { As[r * 17 + 4 * qq + x] = av[b][x]; Cs[r * 16 + 4 * qq + x] = cv[b][x]; }
+            wave_lds_sync();
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+              const int a = As[r * 17 + kk];
+              const int* cr = Cs + kk * 16 + 4 * qq;
+              acc0 = min(acc0, a + cr[0]); acc1 = min(acc1, a + cr[1]); acc2 = min(acc2, a + cr[2]); acc3 = min(acc3, a + cr[3]);
+            }
+          }
+        }
+        int* dst = sm.dfar[t][bj & 3] + r * 16 + 4 * qq;
+        if (acc0 < HALF) atomicMin(dst, acc0);
+        if (acc1 < HALF) atomicMin(dst + 1, acc1);
+        if (acc2 < HALF) atomicMin(dst + 2, acc2);
+        if (acc3 < HALF) atomicMin(dst + 3, acc3);
       } else {
-        mfe_e_item_rows(sm, it - nK, d, par, pcnt, sh, lane, TermAU, e_bulge1, e_int23, P - 1);
+        mfe_e_item_rows(sm, it - nKF, d, par, pcnt, sh, lane, TermAU, e_bulge1, e_int23, P - 1);
       }
     }
   };
@@ -401,13 +504,45 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       sa_f = __builtin_amdgcn_readfirstlane(ld_agent(up_flag));
     }
     if (k + 1 < n_loc) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
+    if (MSTRIP_FARK) {
+      // far items of step k+1: the tiles (t, bj) whose first cell is due far_lat(t) diagonals later; their LDS slots start at INF
+      const int dn = k + 1;
+      int cnt = 0;
+      if (dn < n_loc) {
+        const int ntile = (wid + 15) >> 4;
+        for (int t = 0; t < ntile; t++) {
+          const int imax = min(c0 + 16 * t + 15, c1);
+          // a tile's products are dealt to two steps: the lower half of its k-blocks far_lat(t) diagonals before its first
+          // cell is due (the slot is set to INF one step earlier, i.e. here), the upper half one step later
+#pragma unroll
+          for (int half = 0; half < 2; half++) {
+            const int jmin = dn - half + far_lat(t) + imax;
+            int bk_lo, bk_hi;
+            if ((jmin & 15) == 0 && jmin <= n && far_blocks(c0, c1, t, jmin >> 4, bk_lo, bk_hi)) {
+              const int bj = jmin >> 4;
+              if (half == 0) {
+                int* slot = sm.dfar[t][bj & 3];
+                slot[lane] = INF; slot[lane + 64] = INF; slot[lane + 128] = INF; slot[lane + 192] = INF;
+              }
+              const int mid = bk_lo + ((bk_hi - bk_lo + 1) >> 1);           // lower half: bk_lo .. mid-1, upper: mid .. bk_hi
+              const int f0 = half ? mid : bk_lo, f1 = half ? bk_hi : mid - 1;
+              for (int b0 = f0; b0 <= f1 && cnt < FAR_TAB; b0 += FAR_CH) {
+                if (lane == 0) sm.far_tab[dn & 1][cnt] = t | (bj << 4) | (b0 << 12) | (min(FAR_CH, f1 - b0 + 1) << 20);
+                cnt++;
+              }
+            }
+          }
+        }
+      }
+      if (lane == 0) sm.far_cnt[dn & 1] = cnt;
+    }
   };
   // B: pairable list of diagonal k+1 (entries beyond the count are never read, so the rows do not wait for it); exterior
   //    column j = k-3 (last strip).  Both requested one step ahead: lp_* / fx_*.
   constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
   int lp_cnt = 0, lp_p0 = 0, lp_p1 = 0, lp_x0 = 0, lp_x1 = 0, fx[NFX];
   auto sb_request = [&](const int k) {                                // for step k: list of diagonal k+1, column k-3
-    if (k + 1 < n_loc) {
+    if (!(MSTRIP_SKIP & 64) && k + 1 < n_loc) {
       const int32_t* row = PL + (k + 1) * ld + c0 - 1;
       const int32_t* rowx = PLX + (k + 1) * ld + c0 - 1;
       lp_cnt = PLC[(k + 1) * STRIP_MAXS + s];
@@ -415,7 +550,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       lp_x0 = rowx[lane]; lp_x1 = rowx[min(lane + WAVE, wid)];
     }
     const int j = k - 3, fcnt = j - TURN - 1;
-    const int nch = (last && j >= TURN + 2) ? (fcnt + WAVE - 1) >> 6 : 0;
+    const int nch = (!(MSTRIP_SKIP & 32) && last && j >= TURN + 2) ? (fcnt + WAVE - 1) >> 6 : 0;
 #pragma unroll
     for (int c = 0; c < NFX; c++) {
       fx[c] = INF;
@@ -425,17 +560,27 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   if (wave == w_svcB) sb_request(TURN + 1);
   auto service_b = [&](const int k) {
     const int dn = k + 1, j = k - 3, fcnt = j - TURN - 1;
-    if (k + 1 < n_loc) {
+    if (!(MSTRIP_SKIP & 64) && k + 1 < n_loc) {
       sm.plist[dn & 1][lane] = lp_p0; sm.xe[dn & 1][lane] = lp_x0;
       if (lane + WAVE < SM::NL) { sm.plist[dn & 1][lane + WAVE] = lp_p1; sm.xe[dn & 1][lane + WAVE] = lp_x1; }
       if (lane == 0) { sm.pcnt[dn & 1] = lp_cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
     }
-    if (last && j >= TURN + 2) {
+    if (!(MSTRIP_SKIP & 32) && last && j >= TURN + 2) {
+      // (the LDS reads first, all of them, under wave-uniform conditions: one read per chunk inside a per-lane condition
+      // made fifteen dependent LDS round trips of this job -- 2.3 k cycles of every step of the last strip)
+      const int nch = (fcnt + WAVE - 1) >> 6;
+      int fv[NFX];
+#pragma unroll
+      for (int c = 0; c < NFX; c++) {
+        fv[c] = 0;
+        if (c < nch) fv[c] = sm.f5[min(lane + 1 + c * WAVE, fcnt) - 1];
+      }
       int m = INF;
 #pragma unroll
       for (int c = 0; c < NFX; c++) {
         const int i = lane + 1 + c * WAVE;
-        if (c * WAVE < fcnt && i <= fcnt && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
+        const int v = fv[c] + fx[c];
+        m = (c < nch && i <= fcnt && fx[c] < HALF && v < m) ? v : m;
       }
       m = wave_min_i32(m);
       const int prev = sm.f5[j - 1];
@@ -495,7 +640,13 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
             if (fb < HALF) f = min(f, fb + MLbase);
           }
           if (c < INF) f = min(f, c + MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
-          const int dec = aK >= HALF ? INF : aK;
+          int aKf = aK;
+          if (MSTRIP_FARK) {
+            int bk_lo, bk_hi;
+            const int tI = (i - 1) >> 4;
+            if (far_blocks(c0, c1, tI, jg >> 4, bk_lo, bk_hi)) aKf = min(aKf, sm.dfar[tI][(jg >> 4) & 3][((i - 1) & 15) * 16 + (jg & 15)]);
+          }
+          const int dec = aKf >= HALF ? INF : aKf;
           sm.dml[(d & 3) * RS + i] = dec;
           const int fv = min(f, dec);
           sm.fmlrow[d & 1][i] = fv;

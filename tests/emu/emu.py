@@ -10,13 +10,15 @@ _LIB = os.path.join(_HERE, "libemu.so")
 _CSRC = os.path.join(_HERE, "..", "..", "desirna_amd", "csrc")
 
 
-def build():
+def build(flags=(), tag=""):
+    """flags: extra -D options (a build of its own, libemu<tag>.so): experimental code paths of the kernels"""
+    lib = _LIB if not tag else _LIB.replace(".so", tag + ".so")
     srcs = [os.path.join(_HERE, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
     srcs += [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hpp")]
-    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", _LIB,
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread"] + list(flags) + ["-o", lib,
                                os.path.join(_HERE, "emu_kernels.cpp")])
-    L = C.CDLL(_LIB)
+    L = C.CDLL(lib)
     vp, ci = C.c_void_p, C.c_int
     L.emu_mfe.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, vp, vp, vp, vp, vp]
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
@@ -33,8 +35,8 @@ def build():
 
 
 class Emu:
-    def __init__(self, blob):
-        self.L = build()
+    def __init__(self, blob, flags=(), tag=""):
+        self.L = build(flags, tag)
         self.blob = np.ascontiguousarray(blob, dtype=np.int32)
 
     def mfe(self, seqs, pk_rounds=0, nt=128, dump=False):
