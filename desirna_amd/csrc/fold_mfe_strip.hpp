@@ -75,9 +75,10 @@ struct MfeStripSmem {
   int dml[4 * RS];               // decomposition minima of the last 4 diagonals
   int fmlrow[2][RS];             // fML of the last two diagonals
   int accG[2][P], accI[2][P], accK[2][P];
-  int dfar[P / 16][4][256];      // far part of the split minimum of a tile: [tile row][16-block of j & 3][16 x 16 cells]
-  int fstage[NW][16 * 17 + 256]; // per wave: the two operand tiles of a tile product
-  int far_tab[2][FAR_TAB];       // far items of the step: tile row | j-block << 4 | first k-block << 12 | k-blocks << 20
+  // blocked multiloop splits (MSTRIP_FARK; one element each when off)
+  int dfar[MSTRIP_FARK ? P / 16 : 1][MSTRIP_FARK ? 4 : 1][MSTRIP_FARK ? 256 : 1];   // far part of the split minimum of a tile: [tile row][16-block of j & 3][16 x 16 cells]
+  int fstage[MSTRIP_FARK ? NW : 1][MSTRIP_FARK ? 16 * 17 + 256 : 1];              // per wave: the two operand tiles of a tile product
+  int far_tab[2][MSTRIP_FARK ? FAR_TAB : 1];   // far items of the step: tile row | j-block << 4 | first k-block << 12 | k-blocks << 20
   int far_cnt[2];
   int gimp[2][NG][GSLOTS + 2];   // minima of the tower that enters the strip, staged by the service wave
   int xtab[64 + 1024 + 128 + 128];
@@ -113,18 +114,11 @@ __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j
     fx[c] = INF_DEV;
     if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
   }
-  int fv[NFX];
-#pragma unroll
-  for (int c = 0; c < NFX; c++) {
-    fv[c] = 0;
-    if (c < nch) fv[c] = sm.f5[min(lane + 1 + c * WAVE, cnt) - 1];
-  }
   int m = INF_DEV;
 #pragma unroll
   for (int c = 0; c < NFX; c++) {
     const int i = lane + 1 + c * WAVE;
-    const int v = fv[c] + fx[c];
-    m = (c < nch && i <= cnt && fx[c] < INF_DEV / 2 && v < m) ? v : m;
+    if (c < nch && i <= cnt && fx[c] < INF_DEV / 2) m = min(m, sm.f5[i - 1] + fx[c]);
   }
   m = wave_min_i32(m);
   const int prev = sm.f5[j - 1];
@@ -339,10 +333,16 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     const int tmax = d - TURN - 2;
     // near split points: everything while no tile can have far blocks yet (d < 57), else the two ends of the range (the far
     // blocks start <= 63 and end <= 80 split points from the ends; what a far block covers is masked per cell)
+#if MSTRIP_FARK
     const bool two = MSTRIP_FARK && tmax > 63 + 16 && d - 80 > 64;
     const int nterm = two ? 60 + (tmax - (d - 80) + 1) : tmax - TURN;
     const int kssh = nterm > 96 ? 3 : nterm > 48 ? 2 : nterm > 24 ? 1 : 0;
     const int KS = 1 << kssh, KG = 4 << kssh;
+#else
+    const int kssh = d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0;
+    const int KS = 1 << kssh, KG = 4 << kssh;
+    const int astep = 4 * KG * ld, cstep = 4 * KG * (ld - 1);
+#endif
     const int nK = (MSTRIP_SKIP & 1) ? 0 : ((ncell + 63) >> 6) << kssh, nE = (MSTRIP_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
     const int nF = (MSTRIP_FARK && !(MSTRIP_SKIP & 16)) ? __builtin_amdgcn_readfirstlane(sm.far_cnt[par]) : 0;
     const int nKF = nK + nF;
@@ -356,6 +356,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     };
     for (int it = pop(); it < nItems; it = pop()) {
       if (decltype(with_k)::value && it >= nF && it < nKF) {
+#if MSTRIP_FARK
         const int itk = it - nF;
         const int g = (itk & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
         int i = ((itk >> kssh) << 6) + 4 * cl + 1;
@@ -396,6 +397,36 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           }
         }
 #undef NEARV
+#else
+        const int tmax_ = tmax;
+        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+        int i = ((it >> kssh) << 6) + 4 * cl + 1;
+        const bool act = i <= ncell;
+        i = act ? i : 1;
+        const int ig = i + c0 - 1;
+        int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
+        int tt = TURN + 1 + g;
+        const int tmax = tmax_;
+        int vA = (tt * ld + ig) * 4;                               // fML[i .. i+3, . + tt]
+        int vC = ((d - tt - 1) * ld + ig + tt + 1) * 4;            // fML[i+tt+1 .. , j ..]
+        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
+          const int vCl = vC - 3 * cstep;
+          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vCl, 3 * cstep);
+          const i32x4 a1 = buf_load_i32x4(rsF, vA, astep), c1v = buf_load_i32x4_sc1(rsF, vCl, 2 * cstep);
+          const i32x4 a2 = buf_load_i32x4(rsF, vA, 2 * astep), c2v = buf_load_i32x4_sc1(rsF, vCl, cstep);
+          const i32x4 a3 = buf_load_i32x4(rsF, vA, 3 * astep), c3v = buf_load_i32x4_sc1(rsF, vCl, 0);
+          vA += 4 * astep; vC -= 4 * cstep;
+          m0 = min(m0, min(min(a0.x + c0v.x, a1.x + c1v.x), min(a2.x + c2v.x, a3.x + c3v.x)));
+          m1 = min(m1, min(min(a0.y + c0v.y, a1.y + c1v.y), min(a2.y + c2v.y, a3.y + c3v.y)));
+          m2 = min(m2, min(min(a0.z + c0v.z, a1.z + c1v.z), min(a2.z + c2v.z, a3.z + c3v.z)));
+          m3 = min(m3, min(min(a0.w + c0v.w, a1.w + c1v.w), min(a2.w + c2v.w, a3.w + c3v.w)));
+        }
+        for (; tt <= tmax; tt += KG) {
+          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vC, 0);
+          m0 = min(m0, a0.x + c0v.x); m1 = min(m1, a0.y + c0v.y); m2 = min(m2, a0.z + c0v.z); m3 = min(m3, a0.w + c0v.w);
+          vA += astep; vC -= cstep;
+        }
+#endif
         // the four 16-lane rows hold different split points of the same cells
         m0 = min(m0, __shfl_xor(m0, 16)); m1 = min(m1, __shfl_xor(m1, 16)); m2 = min(m2, __shfl_xor(m2, 16)); m3 = min(m3, __shfl_xor(m3, 16));
         m0 = min(m0, __shfl_xor(m0, 32)); m1 = min(m1, __shfl_xor(m1, 32)); m2 = min(m2, __shfl_xor(m2, 32)); m3 = min(m3, __shfl_xor(m3, 32));
@@ -405,7 +436,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           if (i + 2 <= ncell && m2 < HALF) atomicMin(&sm.accK[par][(i + 2 + sh) & (P - 1)], m2);
           if (i + 3 <= ncell && m3 < HALF) atomicMin(&sm.accK[par][(i + 3 + sh) & (P - 1)], m3);
         }
-      } else if (decltype(with_k)::value && it < nF) {
+      } else if (MSTRIP_FARK && decltype(with_k)::value && it < nF) {
         // ---- far item (first in the queue: its loads come from beyond the L2): nb tile products of tile (t, bj), k-blocks b0 ..: lane (r, q) = row r of the tile, columns 4q .. 4q+3
         const int e = sm.far_tab[par][it];
         const int t = e & 15, bj = (e >> 4) & 255, b0 = (e >> 12) & 255, nb = (e >> 20) & 15;
@@ -566,21 +597,11 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       if (lane == 0) { sm.pcnt[dn & 1] = lp_cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
     }
     if (!(MSTRIP_SKIP & 32) && last && j >= TURN + 2) {
-      // (the LDS reads first, all of them, under wave-uniform conditions: one read per chunk inside a per-lane condition
-      // made fifteen dependent LDS round trips of this job -- 2.3 k cycles of every step of the last strip)
-      const int nch = (fcnt + WAVE - 1) >> 6;
-      int fv[NFX];
-#pragma unroll
-      for (int c = 0; c < NFX; c++) {
-        fv[c] = 0;
-        if (c < nch) fv[c] = sm.f5[min(lane + 1 + c * WAVE, fcnt) - 1];
-      }
       int m = INF;
 #pragma unroll
       for (int c = 0; c < NFX; c++) {
         const int i = lane + 1 + c * WAVE;
-        const int v = fv[c] + fx[c];
-        m = (c < nch && i <= fcnt && fx[c] < HALF && v < m) ? v : m;
+        if (c * WAVE < fcnt && i <= fcnt && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
       }
       m = wave_min_i32(m);
       const int prev = sm.f5[j - 1];

@@ -437,19 +437,11 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
       if (lane == 0) { sm.pcnt[dn & 1] = cnt; sm.qk[dn & 1] = 0; sm.qe[dn & 1] = 0; }
     }
     if (do_q5) {
-      // (LDS reads first, under wave-uniform conditions: inside per-lane conditions they were dependent round trips)
-      double qv[NFX];
-#pragma unroll
-      for (int c = 0; c < NFX; c++) {
-        qv[c] = 0.0;
-        if (c < nch) qv[c] = sm.q5[min(lane + 1 + c * WAVE, fcnt) - 1];
-      }
       double sacc = 0.0;
 #pragma unroll
       for (int c = 0; c < NFX; c++) {
         const int i = lane + 1 + c * WAVE;
-        const double term = qv[c] * fx[c];
-        sacc += (c < nch && i <= fcnt) ? term : 0.0;
+        if (c < nch && i <= fcnt) sacc += sm.q5[i - 1] * fx[c];
       }
       sacc = wave_sum_f64(sacc);
       sm.q5[j] = sm.q5[j - 1] * sc1 + sacc;
