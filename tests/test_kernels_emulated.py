@@ -225,10 +225,10 @@ def test_two_workgroup_mfe_kernel(emu, oracle, L, nt, pk):
 
 def test_pf_strip_kernel(emu, oracle):
     """fold_pf_strip.hpp on the CPU: the three strips of a sequence run side by side (OS threads), records and flags go
-    through ordinary memory; the second call exercises the epoch arithmetic of the never-reset flags.  110 nt at 256 threads:
-    strips of 37 columns (a halo reaches 31), towers that walk through all three strips, multiloop sums dealt 1 / 2 / 4 ways."""
+    through ordinary memory; the second call exercises the epoch arithmetic of the never-reset flags.  100 nt at 256 threads:
+    strips of 33 / 34 columns (a halo reaches 31), towers that walk through all three strips, multiloop sums dealt 1 / 2 / 4 ways."""
     rng = np.random.default_rng(4110)
-    seqs = [_rand(rng, 110, "GGCCAU")]
+    seqs = [_rand(rng, 100, "GGCCAU")]
     Ep, st = emu.pf_strip(seqs, 3, nt=256, calls=2)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
@@ -240,7 +240,7 @@ def test_mfe_strip_kernel(emu, oracle):
     "launch" on the tables they left behind; energies and pk-annotated structures must equal the oracle's; a bad character is
     reported by the traceback kernel."""
     rng = np.random.default_rng(4111)
-    seqs = [_rand(rng, 100, "GGCCAU")]
+    seqs = [_rand(rng, 84, "GGCCAU")]
     E, ss, st = emu.mfe_strip(seqs, 2, pk_rounds=3, nt=256, calls=1)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
@@ -253,10 +253,10 @@ def test_mfe_strip_kernel(emu, oracle):
 def test_mfe_strip_kernel_blocked_splits(blob, oracle):
     """The blocked form of the multiloop splits in fold_mfe_strip.hpp (-DMSTRIP_FARK=1: 16 x 16 tiles of cells, far k-blocks as
     tile products through LDS, near split points masked per cell; off by default: correct but not yet faster):
-    energies and structures must equal the oracle's.  150 nt in three strips: far blocks exist from diagonal ~57 on."""
+    energies and structures must equal the oracle's.  124 nt in three strips: far blocks exist from diagonal ~57 on."""
     emu_f = Emu(blob, flags=("-DMSTRIP_FARK=1",), tag="_fark")
     rng = np.random.default_rng(4112)
-    seqs = [_rand(rng, 150, "GGCCAU")]
+    seqs = [_rand(rng, 124, "GGCCAU")]
     E, ss, st = emu_f.mfe_strip(seqs, 3, pk_rounds=0, nt=256, calls=1)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
