@@ -167,10 +167,10 @@ static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, i
   StripLink lk;
   lk.flags = e->d_sflags + (size_t)first_slot * STRIP_MAXS * 32;
   lk.base = next_strip_epoch(e);
-  lk.nseq = nseq; lk.S = S; lk.idx = idx;
+  lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S);
   lk.dbg = e->d_sdbg ? e->d_sdbg + (size_t)first_slot * 8 : nullptr;
   const int groups = (nseq + 7) / 8;
-  hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * (S + STRIP_PAD)), dim3(1024), 0, st, a, lk);
+  hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk);
 }
 
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
@@ -183,10 +183,10 @@ static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S,
     StripLink lk;
     lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
     lk.base = next_strip_epoch(e);
-    lk.nseq = nseq; lk.S = S; lk.idx = idx;
+    lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S);
     lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
     lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
-    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + STRIP_PAD)), dim3(1024), 0, st, a, lk, xr, round);
+    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
     hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round);
   }
 }

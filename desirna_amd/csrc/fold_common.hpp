@@ -268,10 +268,16 @@ __device__ __forceinline__ int rtype_of(int t) {
 // behind each other on a quarter of the CUs and the rest idles (measured: tools/strip_clocks.py).  One empty block per
 // sequence rotates the assignment.
 constexpr int STRIP_PAD = DRNA_STRIP_PAD;
+// ... so that S + pad is ODD: with an even number of blocks per sequence the strips still fall on the same engines in turn
+// (three strips + one empty block: strip s of every sequence on engine s again, n = 300 at R = 128: PF 2.58 vs 2.07 ms)
+__host__ __device__ inline int strip_pad(int S) { return STRIP_PAD ? ((S & 1) ? 0 : 1) : 0; }
 constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
 constexpr int STRIP_REC = 88;                         // doubles per exchange record
 constexpr int STRIP_MAXS = 8;                         // strips per sequence at most
-constexpr int STRIP_WMAX = 120;                       // widest strip of the production kernel (1024 threads)
+#ifndef DRNA_STRIP_WMAX
+#define DRNA_STRIP_WMAX 120
+#endif
+constexpr int STRIP_WMAX = DRNA_STRIP_WMAX;                       // widest strip of the production kernel (1024 threads)
 constexpr int STRIP_NMAX = STRIP_MAXS * STRIP_WMAX;   // longest sequence
 
 struct StripLink {
@@ -279,6 +285,7 @@ struct StripLink {
   int base = 0;              // epoch << 12
   int nseq = 0;              // sequences of this launch
   int S = 0;                 // strips per sequence
+  int pad = 0;               // empty blocks per sequence behind its strips (see strip_pad)
   const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null
   int* dbg = nullptr;        // diagnostics: 8 words per sequence slot, written by a strip whose wait failed
   long long* clk = nullptr;  // diagnostics: start / end wall clock (100 MHz) of every strip workgroup, [slot][STRIP_MAXS][2]

@@ -773,7 +773,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 template <int NT>
 __global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
   __shared__ MfeStripSmem<NT> sm;
-  const int b = blockIdx.x, per = 8 * (lk.S + STRIP_PAD);
+  const int b = blockIdx.x, per = 8 * (lk.S + lk.pad);
   const int grp = b / per, x = b - grp * per;
   const int q = grp * 8 + (x & 7), s = x >> 3;
   if (q >= lk.nseq || s >= lk.S) return;          // (padding blocks: see STRIP_PAD)

@@ -610,7 +610,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
 template <int NT>
 __global__ __launch_bounds__(NT) void pf_strip_kernel(PfArgs A, StripLink lk) {
   __shared__ PfStripSmem<NT> sm;
-  const int b = blockIdx.x, per = 8 * (lk.S + STRIP_PAD);
+  const int b = blockIdx.x, per = 8 * (lk.S + lk.pad);
   const int grp = b / per, x = b - grp * per;
   const int q = grp * 8 + (x & 7), s = x >> 3;
   if (q >= lk.nseq || s >= lk.S) return;          // (padding blocks: see STRIP_PAD)
