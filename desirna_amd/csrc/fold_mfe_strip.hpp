@@ -13,6 +13,7 @@
 // the structure found so far (the output string itself) is the state that masks the next round.
 #pragma once
 #include "fold_mfe_lds.hpp"
+#include <type_traits>
 
 namespace drna {
 
@@ -29,6 +30,9 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize
 #endif
 
+#ifndef MSTRIP_KU
+#define MSTRIP_KU 8       // split points per lane and round trip in the big batches (2 x 16-byte loads each)
+#endif
 #ifndef MSTRIP_FARK
 #define MSTRIP_FARK 0        // 1 = multiloop splits in blocked form (see far_blocks): correct, not yet faster; 0 = every split point per diagonal
 #endif
@@ -409,23 +413,29 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
         const int tmax = tmax_;
         int vA = (tt * ld + ig) * 4;                               // fML[i .. i+3, . + tt]
         int vC = ((d - tt - 1) * ld + ig + tt + 1) * 4;            // fML[i+tt+1 .. , j ..]
-        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
-          const int vCl = vC - 3 * cstep;
-          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vCl, 3 * cstep);
-          const i32x4 a1 = buf_load_i32x4(rsF, vA, astep), c1v = buf_load_i32x4_sc1(rsF, vCl, 2 * cstep);
-          const i32x4 a2 = buf_load_i32x4(rsF, vA, 2 * astep), c2v = buf_load_i32x4_sc1(rsF, vCl, cstep);
-          const i32x4 a3 = buf_load_i32x4(rsF, vA, 3 * astep), c3v = buf_load_i32x4_sc1(rsF, vCl, 0);
-          vA += 4 * astep; vC -= 4 * cstep;
-          m0 = min(m0, min(min(a0.x + c0v.x, a1.x + c1v.x), min(a2.x + c2v.x, a3.x + c3v.x)));
-          m1 = min(m1, min(min(a0.y + c0v.y, a1.y + c1v.y), min(a2.y + c2v.y, a3.y + c3v.y)));
-          m2 = min(m2, min(min(a0.z + c0v.z, a1.z + c1v.z), min(a2.z + c2v.z, a3.z + c3v.z)));
-          m3 = min(m3, min(min(a0.w + c0v.w, a1.w + c1v.w), min(a2.w + c2v.w, a3.w + c3v.w)));
-        }
-        for (; tt <= tmax; tt += KG) {
-          const i32x4 a0 = buf_load_i32x4(rsF, vA, 0), c0v = buf_load_i32x4_sc1(rsF, vC, 0);
-          m0 = min(m0, a0.x + c0v.x); m1 = min(m1, a0.y + c0v.y); m2 = min(m2, a0.z + c0v.z); m3 = min(m3, a0.w + c0v.w);
-          vA += astep; vC -= cstep;
-        }
+        // split points in batches of KU (16 loads in flight), then 4, then the last <= 3 at once (masked): every batch is ONE
+        // round trip to L2, and the round trips are what a split item costs
+        auto batch = [&](auto nu, const int nvalid) {
+          constexpr int U = decltype(nu)::value;
+          i32x4 a[U], c[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const bool on = u < nvalid;
+            a[u] = buf_load_i32x4(rsF, on ? vA + u * astep : vA, 0);
+            c[u] = buf_load_i32x4_sc1(rsF, on ? vC - u * cstep : vC, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const bool on = u < nvalid;
+            m0 = min(m0, on ? a[u].x + c[u].x : INF); m1 = min(m1, on ? a[u].y + c[u].y : INF);
+            m2 = min(m2, on ? a[u].z + c[u].z : INF); m3 = min(m3, on ? a[u].w + c[u].w : INF);
+          }
+          vA += U * astep; vC -= U * cstep; tt += U * KG;
+        };
+        constexpr int KU = MSTRIP_KU;
+        for (; tt + (KU - 1) * KG <= tmax;) batch(std::integral_constant<int, KU>{}, KU);
+        for (; tt + 3 * KG <= tmax;) batch(std::integral_constant<int, 4>{}, 4);
+        if (tt <= tmax) batch(std::integral_constant<int, 3>{}, (tmax - tt) / KG + 1);
 #endif
         // the four 16-lane rows hold different split points of the same cells
         m0 = min(m0, __shfl_xor(m0, 16)); m1 = min(m1, __shfl_xor(m1, 16)); m2 = min(m2, __shfl_xor(m2, 16)); m3 = min(m3, __shfl_xor(m3, 16));
