@@ -94,6 +94,9 @@ struct drna_engine {
   // strip kernels (fold_pf_strip.hpp: 200 < n <= 960, several workgroups per sequence): one flag line per (sequence, strip)
   int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
   int strip_epoch = 0;            // grows by one per call; flags are never reset
+  int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
+  int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
+  bool in_fallback = false;
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
   int32_t* d_srec = nullptr;      // MFE strips: exchange records and list counts, srec_stride int32 per sequence
   long long srec_stride = 0;
@@ -167,7 +170,7 @@ static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, i
   StripLink lk;
   lk.flags = e->d_sflags + (size_t)first_slot * STRIP_MAXS * 32;
   lk.base = next_strip_epoch(e);
-  lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S);
+  lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
   lk.dbg = e->d_sdbg ? e->d_sdbg + (size_t)first_slot * 8 : nullptr;
   const int groups = (nseq + 7) / 8;
   hipLaunchKernelGGL(pf_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk);
@@ -183,7 +186,7 @@ static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S,
     StripLink lk;
     lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
     lk.base = next_strip_epoch(e);
-    lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S);
+    lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
     lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
     lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
     hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
@@ -291,6 +294,7 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
+  if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
 }
@@ -302,6 +306,14 @@ extern "C" int drna_debug_strip_clocks(drna_engine* e, long long* out, int nslot
   const int m = std::min(nslots, e->max_R);
   if (hipMemcpy(out, e->d_sclk, (size_t)m * STRIP_MAXS * 2 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return m;
+}
+
+extern "C" int drna_get_option(const drna_engine* e, const char* name, int* value) {
+  if (!e || !name || !value) return DRNA_ERR_ARG;
+  if (!strcmp(name, "dual")) { *value = e->dual ? (e->dual_force ? 2 : 1) : 0; return DRNA_OK; }
+  if (!strcmp(name, "strips")) { *value = e->strips; return DRNA_OK; }
+  if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
+  return DRNA_ERR_ARG;
 }
 
 extern "C" const char* drna_last_error(const drna_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -496,6 +508,17 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       snprintf(buf, sizeof buf, "sequence %d: partition function left the fp64 range (pf_scale too small/large)", r);
       e->err = buf;
       return DRNA_ERR_PF_RANGE;
+    }
+    if (st == ST_SYNC && !e->in_fallback) {
+      // HIP promises no dispatch order: a multi-workgroup fold whose bounded wait expired is not an error of the batch -- the
+      // whole call is redone with one workgroup per fold (general / LDS-resident kernels), which need nobody
+      const int s_strips = e->strips;
+      const bool s_dual = e->dual;
+      e->in_fallback = true; e->strips = 0; e->dual = false;
+      const int rc = drna_score_batch_device(e, R, L, d_seqs, flags, d_Epf, d_Emfe, d_mfe_ss, d_Ed);
+      e->strips = s_strips; e->dual = s_dual; e->in_fallback = false;
+      e->sync_fallbacks++;
+      return rc;
     }
     if (st == ST_SYNC) {
       snprintf(buf, sizeof buf, "sequence %d: the workgroups of the fold lost each other (a wait expired)", r);
@@ -859,6 +882,14 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
     const int st = sm != ST_OK ? sm : sp;
     if (st == ST_OK) continue;
+    if (st == ST_SYNC && !e->in_fallback) {               // (see drna_score_batch_device)
+      const int s_strips = e->strips;
+      e->in_fallback = true; e->strips = 0;
+      const int rc = drna_score_ragged(e, R, lens, seqs, target_of, flags, Epf, Emfe, mfe_ss, Ed);
+      e->strips = s_strips; e->in_fallback = false;
+      e->sync_fallbacks++;
+      return rc;
+    }
     char buf[160];
     snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
                               : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"

@@ -179,6 +179,10 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   const bool has_up = c1 < n, has_down = c0 > 1, last = !has_down;
   const int n_loc_up = n_loc - wid;
   int* const my_flag = lk.flags + ((long long)q * STRIP_MAXS + s) * 32;
+  if (lk.fault && s == 0 && c1 == n && c0 > 1) {        // injected fault: the strips below see FAIL, the engine falls back
+    if (threadIdx.x == 0) st_agent(my_flag, lk.base + STRIP_FAIL);
+    return;
+  }
   const int* const up_flag = lk.flags + ((long long)q * STRIP_MAXS + (s > 0 ? s - 1 : 0)) * 32;
 
   int32_t* base = A.ws + (long long)r * A.ws_stride;

@@ -114,6 +114,10 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   const bool has_up = c1 < n, has_down = c0 > 1;
   const int n_loc_up = n_loc - wid;                       // suffix length of the strip above
   int* const my_flag = lk.flags + ((long long)q * STRIP_MAXS + s) * 32;
+  if (lk.fault && s == 0 && c1 == n && c0 > 1) {        // injected fault: the strips below see FAIL, the engine falls back
+    if (threadIdx.x == 0) st_agent(my_flag, lk.base + STRIP_FAIL);
+    return;
+  }
   const int* const up_flag = lk.flags + ((long long)q * STRIP_MAXS + (s > 0 ? s - 1 : 0)) * 32;
 
   double* base = A.ws + (long long)r * A.ws_stride;

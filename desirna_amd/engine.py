@@ -25,7 +25,7 @@ EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
            "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
-           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums", "drna_debug_strip_clocks")
+           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums", "drna_debug_strip_clocks", "drna_get_option")
 
 RNG_WORDS = 625        # DRNA_RNG_WORDS: uint32 words of one replica's MT19937 stream
 
@@ -65,6 +65,8 @@ def load_library(path=None):
     L.drna_timing_sums.argtypes = [vp, vp, ci]
     L.drna_set_option.restype = ci
     L.drna_set_option.argtypes = [vp, C.c_char_p, ci]
+    L.drna_get_option.restype = ci
+    L.drna_get_option.argtypes = [vp, C.c_char_p, vp]
     L.drna_ensemble_defect_batch.restype = ci
     L.drna_ensemble_defect_batch.argtypes = [vp, ci, ci, C.c_char_p, vp, vp]
     L.drna_ensemble_defect_batch_device.restype = ci
@@ -118,6 +120,12 @@ class Engine:
     def set_option(self, name, value):
         """Engine option (``drna_set_option``): ``"dual"`` = fold small batches with two workgroups per sequence (default on)."""
         self._check(self._L.drna_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        """Reads an option back, or the counter ``"sync_fallbacks"`` (``drna_get_option``)."""
+        v = C.c_int(0)
+        self._check(self._L.drna_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

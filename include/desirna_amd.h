@@ -178,6 +178,11 @@ int drna_last_edef_timing(const drna_engine *e, float out[2]);
  */
 int drna_set_option(drna_engine *e, const char *name, int value);
 
+/* reads an option back ("dual", "strips"), or the counter "sync_fallbacks": calls in which a fold by several workgroups lost a
+ * partner (a bounded wait expired -- HIP promises no dispatch order) and which were therefore redone, transparently, with one
+ * workgroup per fold.  Option "strip_fault" = 1 injects such a loss into every strip launch (tests). */
+int drna_get_option(const drna_engine *e, const char *name, int *value);
+
 /* diagnostics (engine created with DRNA_STRIP_DEBUG=1 in the environment): start / end wall clocks (100 MHz ticks) of the MFE
  * strip workgroups of the last launch, out[slot][8][2]; returns the number of sequence slots copied (0 without the buffers) */
 int drna_debug_strip_clocks(drna_engine *e, long long *out, int nslots);

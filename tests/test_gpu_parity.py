@@ -681,3 +681,35 @@ def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
     assert a["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == c["Emfe"]).all()
     with pytest.raises(E.EngineError):                   # a bad character is reported by the strip path too
         eng400.score_batch(["ACGU" * 60 + "N" + "ACGU" * 2], E.NEED_MFE | E.NEED_PF)
+
+
+def test_lost_strip_falls_back_to_one_workgroup_per_fold(eng400, oracle):
+    """HIP promises no dispatch order, so a fold by several workgroups may lose a partner (bounded wait -> ST_SYNC).  That must
+    not fail the call: the engine redoes it with one workgroup per fold.  Injected here ("strip_fault": the top strip of every
+    sequence gives up at once): results stay exact, the fallback is counted, and the next call uses the strips again."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(2500)
+    seqs = [_rand(rng, 260) for _ in range(5)]
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_PK
+    before = eng400.get_option("sync_fallbacks")
+    try:
+        eng400.set_option("strip_fault", 1)
+        a = eng400.score_batch(seqs, flags)
+    finally:
+        eng400.set_option("strip_fault", 0)
+    assert eng400.get_option("sync_fallbacks") == before + 1 and eng400.get_option("strips") == 1
+    b = eng400.score_batch(seqs, flags)
+    assert eng400.get_option("sync_fallbacks") == before + 1
+    assert a["mfe_ss"] == b["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all() and np.abs(a["Epf"] - b["Epf"]).max() < 1e-9
+    ss, e = oracle.mfe(seqs[0])
+    assert a["mfe_ss"][0] == oracle.pk_struct(seqs[0], ss) and int(a["Emfe"][0]) == e
+    lens = [260, 100, 301]
+    rs = [_rand(rng, n) for n in lens]
+    try:
+        eng400.set_option("strip_fault", 1)
+        r1 = eng400.score_ragged(rs, flags=E.NEED_PF | E.NEED_MFE)
+    finally:
+        eng400.set_option("strip_fault", 0)
+    r2 = eng400.score_ragged(rs, flags=E.NEED_PF | E.NEED_MFE)
+    assert eng400.get_option("sync_fallbacks") == before + 2
+    assert r1["mfe_ss"] == r2["mfe_ss"] and np.abs(np.array(r1["Epf"]) - np.array(r2["Epf"])).max() < 1e-9
