@@ -91,7 +91,7 @@ struct drna_engine {
   int dual_epoch = 0;             // grows by one per launch; flags are never reset (fold_common.hpp, DualLink)
   int* d_dflags = nullptr;        // [2 kernels][dual_cap][64]
   int32_t *d_xs = nullptr, *d_xa_mfe = nullptr, *d_xb_mfe = nullptr;
-  // strip kernels (fold_pf_strip.hpp: 200 < n <= 960, several workgroups per sequence): one flag line per (sequence, strip)
+  // strip kernels (fold_pf_strip.hpp: 200 < n <= 2046, several workgroups per sequence): one flag line per (sequence, strip)
   int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
   int strip_epoch = 0;            // grows by one per call; flags are never reset
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)

@@ -273,7 +273,7 @@ constexpr int STRIP_PAD = DRNA_STRIP_PAD;
 __host__ __device__ inline int strip_pad(int S) { return STRIP_PAD ? ((S & 1) ? 0 : 1) : 0; }
 constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
 constexpr int STRIP_REC = 88;                         // doubles per exchange record
-constexpr int STRIP_MAXS = 8;                         // strips per sequence at most
+constexpr int STRIP_MAXS = 18;                         // strips per sequence at most
 #ifndef DRNA_STRIP_WMAX
 #define DRNA_STRIP_WMAX 120
 #endif

@@ -1,5 +1,5 @@
 // fold_mfe_strip.hpp -- Zuker MFE fill of ONE sequence by SEVERAL workgroups, each keeping its share of the rings in LDS
-// like fold_mfe_lds.hpp: the path for 200 < n <= 960.  Same recursions, same outputs and the same traceback as fold_mfe.hpp
+// like fold_mfe_lds.hpp: the path for 200 < n <= 2046.  Same recursions, same outputs and the same traceback as fold_mfe.hpp
 // (reference utils/energy_scores.py:151,354).  The decomposition is the one of fold_pf_strip.hpp --
 // strips of columns i, dependencies one way, one exchange record per diagonal and strip boundary, tower minima that walk from
 // strip to strip -- with the min-plus algebra of fold_mfe_lds.hpp:
@@ -109,7 +109,7 @@ __device__ __forceinline__ i32x4 buf_load_i32x4_sc1(RSRC rsrc, int voff, int sof
 // loads, all of them issued before the first is used (a chain of dependent round trips here was the whole step's floor)
 template <class SM, typename RSRC>
 __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j, int lane) {
-  constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+  constexpr int NFX = 15;                             // chunks held in registers at once; longer columns continue in batches of 8
   const int cnt = j - TURN - 1;                       // cells i = 1 .. cnt
   const int nch = (cnt + WAVE - 1) >> 6;
   int fx[NFX];
@@ -123,6 +123,19 @@ __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j
   for (int c = 0; c < NFX; c++) {
     const int i = lane + 1 + c * WAVE;
     if (c < nch && i <= cnt && fx[c] < INF_DEV / 2) m = min(m, sm.f5[i - 1] + fx[c]);
+  }
+  for (int cb = NFX; cb < nch; cb += 8) {             // (columns beyond 960 cells)
+    int gx[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      gx[u] = INF_DEV;
+      if (cb + u < nch) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = lane + 1 + (cb + u) * WAVE;
+      if (cb + u < nch && i <= cnt && gx[u] < INF_DEV / 2) m = min(m, sm.f5[i - 1] + gx[u]);
+    }
   }
   m = wave_min_i32(m);
   const int prev = sm.f5[j - 1];
@@ -584,7 +597,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   };
   // B: pairable list of diagonal k+1 (entries beyond the count are never read, so the rows do not wait for it); exterior
   //    column j = k-3 (last strip).  Both requested one step ahead: lp_* / fx_*.
-  constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+  constexpr int NFX = 15;       // chunks of the exterior column requested ahead (960 cells); longer columns continue inside the step
   int lp_cnt = 0, lp_p0 = 0, lp_p1 = 0, lp_x0 = 0, lp_x1 = 0, fx[NFX];
   auto sb_request = [&](const int k) {                                // for step k: list of diagonal k+1, column k-3
     if (!(MSTRIP_SKIP & 64) && k + 1 < n_loc) {
@@ -616,6 +629,19 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       for (int c = 0; c < NFX; c++) {
         const int i = lane + 1 + c * WAVE;
         if (c * WAVE < fcnt && i <= fcnt && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
+      }
+      for (int cb = NFX; cb * WAVE < fcnt; cb += 8) {             // (columns beyond 960 cells)
+        int gx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          gx[u] = INF;
+          if ((cb + u) * WAVE < fcnt) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = lane + 1 + (cb + u) * WAVE;
+          if ((cb + u) * WAVE < fcnt && i <= fcnt && gx[u] < HALF) m = min(m, sm.f5[i - 1] + gx[u]);
+        }
       }
       m = wave_min_i32(m);
       const int prev = sm.f5[j - 1];

@@ -1,5 +1,5 @@
 // fold_pf_strip.hpp -- McCaskill partition function (inside) of ONE sequence by SEVERAL workgroups, each keeping its share
-// of the rings in LDS like fold_pf_lds.hpp: the path for 200 < n <= 960, where one workgroup's LDS cannot hold a 32-diagonal
+// of the rings in LDS like fold_pf_lds.hpp: the path for 200 < n <= 2046, where one workgroup's LDS cannot hold a 32-diagonal
 // fp64 ring of the whole sequence.  Same recursions and outputs as fold_pf.hpp / fold_pf_lds.hpp (reference
 // utils/energy_scores.py:150 with compute_bpp = 0).
 //
@@ -418,7 +418,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     lp_p0 = row[lane]; lp_p1 = row[min(lane + WAVE, wid)];
   }
   auto service_b = [&](const int k) {
-    constexpr int NFX = (STRIP_NMAX + WAVE - 1) / WAVE;
+    constexpr int NFX = 15;       // chunks of the column held at once (960 cells); longer columns continue in batches of 8
     const bool do_list = k + 1 < n_loc, do_q5 = last && k - 3 >= TURN + 2;
     const int dn = k + 1, j = k - 3;
     const int cnt = lp_cnt, p0 = lp_p0, p1 = lp_p1;
@@ -446,6 +446,19 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
       for (int c = 0; c < NFX; c++) {
         const int i = lane + 1 + c * WAVE;
         if (c < nch && i <= fcnt) sacc += sm.q5[i - 1] * fx[c];
+      }
+      for (int cb = NFX; cb < nch; cb += 8) {                     // (columns beyond 960 cells; same order of additions)
+        double gx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          gx[u] = 0.0;
+          if (cb + u < nch) gx[u] = buf_load_f64_aux(rsX, (j * ld + min(lane + 1 + (cb + u) * WAVE, fcnt)) * 8, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = lane + 1 + (cb + u) * WAVE;
+          if (cb + u < nch && i <= fcnt) sacc += sm.q5[i - 1] * gx[u];
+        }
       }
       sacc = wave_sum_f64(sacc);
       sm.q5[j] = sm.q5[j - 1] * sc1 + sacc;

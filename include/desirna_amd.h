@@ -171,7 +171,7 @@ int drna_last_edef_timing(const drna_engine *e, float out[2]);
  * the MFE fold of every sequence of at least 170 nt is done by TWO workgroups (fold_mfe_dual.hpp).  Results do not depend
  * on it (integer minima: bit-identical).  0 = always one workgroup per sequence, 2 = two workgroups whenever the batch allows,
  * whatever the length.  DRNA_DUAL in the environment sets the default.
- * "strips" (default 1): sequences of 201 .. 960 nt are folded by strips of columns, one workgroup per strip of <= 120 columns
+ * "strips" (default 1): sequences of 201 .. 2046 nt are folded by strips of columns, one workgroup per strip of <= 120 columns
  * (fold_pf_strip.hpp, fold_mfe_strip.hpp), in drna_score_batch* and drna_score_ragged.  MFE energies and structures do not
  * depend on it (bit-identical), Epf agrees to 1e-13 kcal/mol (another summation order).  0 = the general one-workgroup kernels,
  * 2 = two strips also for 64 < n <= 200 (diagnostics).  DRNA_STRIPS in the environment sets the default.
@@ -184,7 +184,7 @@ int drna_set_option(drna_engine *e, const char *name, int value);
 int drna_get_option(const drna_engine *e, const char *name, int *value);
 
 /* diagnostics (engine created with DRNA_STRIP_DEBUG=1 in the environment): start / end wall clocks (100 MHz ticks) of the MFE
- * strip workgroups of the last launch, out[slot][8][2]; returns the number of sequence slots copied (0 without the buffers) */
+ * strip workgroups of the last launch, out[slot][18][2]; returns the number of sequence slots copied (0 without the buffers) */
 int drna_debug_strip_clocks(drna_engine *e, long long *out, int nslots);
 
 /* engine facts: out[0]=device, out[1]=max_R, out[2]=max_L, out[3]=threads per workgroup,

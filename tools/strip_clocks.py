@@ -13,7 +13,7 @@ for R in (64, 128, 256):
     for _ in range(3):
         eng.score_batch(seqs, E.NEED_MFE)
     t = eng.last_timing()["mfe"]
-    out = np.zeros((R, 8, 2), dtype=np.int64)
+    out = np.zeros((R, 18, 2), dtype=np.int64)
     eng._L.drna_debug_strip_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     n = eng._L.drna_debug_strip_clocks(eng._h, out.ctypes.data, R)
     t0 = out[:, :4, 0].min()

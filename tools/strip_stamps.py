@@ -21,7 +21,7 @@ for k, extra in enumerate(sys.argv[1:] or [""]):
         except Exception:
             pass
     t = eng.last_timing()["mfe"]
-    buf = np.zeros((R, 8, 2), dtype=np.int64)
+    buf = np.zeros((R, 18, 2), dtype=np.int64)
     eng._L.drna_debug_strip_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     eng._L.drna_debug_strip_clocks(eng._h, buf.ctypes.data, R)
     st = buf.reshape(-1)[16:16 + 64].reshape(16, 4)
