@@ -57,6 +57,8 @@ struct drna_engine {
   short* d_pt = nullptr;
   int n_targets = 0, L_targets = 0;
   hipStream_t s_mfe = nullptr, s_pf = nullptr, s_eval = nullptr;
+  hipEvent_t ev_mfe2 = nullptr;                // the second half of a batch whose MFE fold takes several launches runs on s_eval (no stream of
+                                               // its own: the runtime maps streams onto a few hardware queues, and streams that share one serialize)
   hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_m0 = nullptr, ev_m1 = nullptr, ev_p0 = nullptr,
              ev_p1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
   float timing[4] = {0, 0, 0, 0};
@@ -95,6 +97,7 @@ struct drna_engine {
   int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
   int strip_epoch = 0;            // grows by one per call; flags are never reset
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
+  int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
   int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
   bool in_fallback = false;
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
@@ -177,21 +180,25 @@ static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, i
 }
 
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
-static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
+// one pseudoknot round of nseq sequences (slots first_slot ...; idx = their sequence numbers, or null: sequences r0 ...)
+static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, int r0,
+                                    hipStream_t st, int round) {
   StripRec xr;
   xr.rec = e->d_srec; xr.stride = e->srec_stride;
   const int groups = (nseq + 7) / 8;
-  if (e->d_sdbg) fprintf(stderr, "mfe strips: rec %p stride %lld max_R %d nseq %d S %d ld %d L %d ws %p\n", (void*)xr.rec, xr.stride, e->max_R, nseq, S, a.ld, a.L, (void*)a.ws);
-  for (int round = 0; round <= a.pk_rounds; round++) {
-    StripLink lk;
-    lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
-    lk.base = next_strip_epoch(e);
-    lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
-    lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
-    lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
-    hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
-    hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round);
-  }
+  StripLink lk;
+  lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
+  lk.base = next_strip_epoch(e);
+  lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.r0 = r0; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
+  lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
+  lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
+  hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
+  hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round, r0);
+}
+// MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
+static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
+  if (e->d_sdbg) fprintf(stderr, "mfe strips: rec %p stride %lld max_R %d nseq %d S %d ld %d L %d ws %p\n", (void*)e->d_srec, e->srec_stride, e->max_R, nseq, S, a.ld, a.L, (void*)a.ws);
+  for (int round = 0; round <= a.pk_rounds; round++) launch_mfe_strips_round(e, a, nseq, S, first_slot, idx, 0, st, round);
 }
 static size_t pf_ws_stride(int ld) { return (size_t)7 * ld * ld + ((size_t)ld * ld + 7) / 8; }  // doubles
 
@@ -248,6 +255,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipStreamCreateWithFlags(&e->s_mfe, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_pf, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->s_eval, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&e->ev_mfe2, hipEventDisableTiming));
   hipEvent_t* evs[] = {&e->ev_start, &e->ev_end, &e->ev_m0, &e->ev_m1, &e->ev_p0, &e->ev_p1, &e->ev_e0, &e->ev_e1,
                        &e->ev_o0, &e->ev_o1, &e->ev_o2};
   for (hipEvent_t* ev : evs) HIP_TRY(hipEventCreate(ev));
@@ -281,6 +289,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   for (void* b : hm)
     if (b) (void)hipHostFree(b);
   hipStream_t ss[] = {e->s_mfe, e->s_pf, e->s_eval};
+  if (e->ev_mfe2) (void)hipEventDestroy(e->ev_mfe2);
   for (hipStream_t s : ss)
     if (s) (void)hipStreamDestroy(s);
   hipEvent_t evs[] = {e->ev_start, e->ev_end, e->ev_m0, e->ev_m1, e->ev_p0, e->ev_p1, e->ev_e0, e->ev_e1,
@@ -295,6 +304,7 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
+  if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
 }
@@ -444,6 +454,15 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       (void)hipMemsetAsync(lk.dbg, 0, 64 * 64 * sizeof(long long), e->s_mfe);
 #endif
       hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_mfe, a, lk);
+    } else if (mfe_strips && a.pk_rounds > 0 && R >= 16 * e->mfe_split && e->mfe_split > 1) {
+      // every round is a fill launch and a traceback launch (one wave per sequence, ~0.2 ms with the chip idle): the batch goes
+      // in parts on two streams, so that one part's traceback runs under another part's fill
+      const int np = e->mfe_split, per = ((R + np - 1) / np + 7) / 8 * 8;
+      for (int round = 0; round <= a.pk_rounds; round++)
+        for (int part = 0, r0 = 0; r0 < R; part++, r0 += per)
+          launch_mfe_strips_round(e, a, std::min(per, R - r0), mfe_strips, r0, nullptr, r0, (part & 1) ? e->s_eval : e->s_mfe, round);
+      HIP_TRY(hipEventRecord(e->ev_mfe2, e->s_eval));
+      HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_mfe2, 0));
     } else if (mfe_strips) launch_mfe_strips(e, a, R, mfe_strips, 0, nullptr, e->s_mfe);
     else if (e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX)
       hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_mfe, a);

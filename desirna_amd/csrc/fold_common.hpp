@@ -287,7 +287,8 @@ struct StripLink {
   int S = 0;                 // strips per sequence
   int pad = 0;               // empty blocks per sequence behind its strips (see strip_pad)
   int fault = 0;             // tests: the top strip of every sequence gives up at once (exercises the engine's fallback)
-  const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null
+  const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null: slot q is sequence q + r0
+  int r0 = 0;
   int* dbg = nullptr;        // diagnostics: 8 words per sequence slot, written by a strip whose wait failed
   long long* clk = nullptr;  // diagnostics: start / end wall clock (100 MHz) of every strip workgroup, [slot][STRIP_MAXS][2]
 };

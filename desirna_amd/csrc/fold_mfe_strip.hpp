@@ -175,7 +175,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   using SM = MfeStripSmem<NT>;
   constexpr int NW = SM::NW, RS = SM::RS, P = SM::P, NFIN = SM::NFIN, NSVC = SM::NSVC, NG = SM::NG;
   const MfeTables& T = *A.T;
-  const int r = lk.idx ? lk.idx[q] : q;
+  const int r = lk.idx ? lk.idx[q] : q + lk.r0;
   if (A.rg.len) A.L = A.rg.len[r];
   const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;
   const int n = A.L, ld = A.ld;
@@ -825,8 +825,8 @@ __global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, St
 // -1 = a strip lost its neighbour; this kernel leaves 1 if another round follows for the sequence, else 0.
 struct MfeTraceSmem : MfeSmemCore<STRIP_NMAX> {};
 
-__device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const int* idx, int q, int round) {
-  const int r = idx ? idx[q] : q;
+__device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const int* idx, int q, int round, int r0 = 0) {
+  const int r = idx ? idx[q] : q + r0;
   if (A.rg.len) A.L = A.rg.len[r];
   const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;
   const int n = A.L, ld = A.ld, lane = lane_id();
@@ -894,10 +894,10 @@ __device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const i
   }
 }
 
-__global__ __launch_bounds__(WAVE) void mfe_strip_trace_kernel(MfeArgs A, const int* idx, int nseq, int round) {
+__global__ __launch_bounds__(WAVE) void mfe_strip_trace_kernel(MfeArgs A, const int* idx, int nseq, int round, int r0) {
   __shared__ MfeTraceSmem sm;
   if ((int)blockIdx.x >= nseq) return;
-  mfe_strip_trace_body(sm, A, idx, blockIdx.x, round);
+  mfe_strip_trace_body(sm, A, idx, blockIdx.x, round, r0);
 }
 
 }  // namespace drna

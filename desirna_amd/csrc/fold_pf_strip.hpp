@@ -100,7 +100,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   using SM = PfStripSmem<NT>;
   constexpr int NW = SM::NW, RS = SM::RS, P = SM::P, NFIN = SM::NFIN, NSVC = SM::NSVC;
   const PfTables& T = *A.T;
-  const int r = lk.idx ? lk.idx[q] : q;
+  const int r = lk.idx ? lk.idx[q] : q + lk.r0;
   if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
   const int tid = threadIdx.x, lane = lane_id();

@@ -95,7 +95,7 @@ static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls) {
         for (int s = 0; s < S; s++) fns.push_back([&, r, s, lk, round]() { mfe_strip_body<NT>(*sms[s], a, lk, xr, r, s, round); });
         emu_launch_many(r * S, NT, fns);
       }
-      for (int r = 0; r < R; r++) emu_launch(r, 64, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round); });
+      for (int r = 0; r < R; r++) emu_launch(r, 64, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round, 0); });
     }
   for (auto* p : sms) delete p;
   delete smt;

@@ -662,6 +662,13 @@ def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
         assert (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all()
         assert np.abs(a["Epf"] - c["Epf"]).max() < 1e-9
         assert a["mfe_ss"] == b["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == c["Emfe"]).all() and (a["Emfe"] == b["Emfe"]).all()
+        if pk and R >= 32:                 # the pseudoknot rounds of such a batch run in two halves on two streams: same answers as in one
+            try:
+                eng.set_option("mfe_split", 1)
+                d1 = eng.score_batch(seqs, flags)
+            finally:
+                eng.set_option("mfe_split", 2)
+            assert d1["mfe_ss"] == a["mfe_ss"] and (d1["Emfe"] == a["Emfe"]).all()
         for k in (0, R - 1):
             assert abs(a["Epf"][k] - oracle.pf(seqs[k])) < 1e-9
             ss, e = oracle.mfe(seqs[k])

@@ -4,13 +4,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from desirna_amd import engine as E
-rng = np.random.default_rng(20260101)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 20260101)
 tg = bench.load_target("eteV1_53.txt"); L = len(tg); R = 128
 seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
 eng = E.Engine(max_R=R, max_L=L)
 eng.set_targets([tg, tg, tg])
-ts = []
-for _ in range(8):
-    eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL | E.NEED_PK)
-    ts.append(eng.last_timing())
-print([round(t["total"], 2) for t in ts], "mfe", round(ts[-1]["mfe"], 2), "pf", round(ts[-1]["pf"], 2))
+ref = None
+for split in (2, 1, 2, 1):
+    eng.set_option("mfe_split", split)
+    ts = []
+    for _ in range(8):
+        out = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL | E.NEED_PK)
+        ts.append(eng.last_timing())
+    if ref is None:
+        ref = out
+    same = out["mfe_ss"] == ref["mfe_ss"] and (out["Emfe"] == ref["Emfe"]).all()
+    print("mfe_split", split, [round(t["total"], 2) for t in ts], "mfe", round(ts[-1]["mfe"], 2), "pf", round(ts[-1]["pf"], 2), "same" if same else "DIFFERENT")
