@@ -410,7 +410,8 @@ def test_small_engines(oracle):
 
 
 def test_maximum_length(oracle):
-    """the engine's length limit (MAXN - 2 = 2046 nt, general kernels): same bits as the oracle"""
+    """the engine's length limit (MAXN - 2 = 2046 nt; 18 strips per fold, and the general one-workgroup kernels with "strips"
+    off): same bits as the oracle"""
     from desirna_amd import engine as E
     rng = np.random.default_rng(4242)
     for L in (601, 2046):
@@ -421,6 +422,9 @@ def test_maximum_length(oracle):
         ss, e = oracle.mfe(seqs[0])
         assert out["mfe_ss"][0] == ss and int(out["Emfe"][0]) == e and int(out["Ed"][0, 0]) == 0
         assert abs(float(out["Epf"][0]) - oracle.pf(seqs[0])) < 1e-9
+        eng.set_option("strips", 0)
+        gen = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+        assert gen["mfe_ss"] == out["mfe_ss"] and int(gen["Emfe"][0]) == int(out["Emfe"][0]) and abs(gen["Epf"][0] - out["Epf"][0]) < 1e-9
         eng.close()
     with pytest.raises(Exception):
         E.Engine(max_R=1, max_L=2047, device=0)
