@@ -37,7 +37,8 @@ print("cases done, mismatches:", bad, "fallbacks:", eng.get_option("sync_fallbac
 for case in range(6):
     lens = [int(x) for x in rng.integers(12, 700, size=int(rng.integers(3, 40)))]
     seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
-    eng.set_option("strips", 1); a = eng.score_ragged(seqs, flags=E.NEED_PF | E.NEED_MFE)
-    eng.set_option("strips", 0); b = eng.score_ragged(seqs, flags=E.NEED_PF | E.NEED_MFE)
+    fl = E.NEED_PF | E.NEED_MFE | (E.NEED_PK if case & 1 else 0)
+    eng.set_option("strips", 1); a = eng.score_ragged(seqs, flags=fl)
+    eng.set_option("strips", 0); b = eng.score_ragged(seqs, flags=fl)
     ok = a["mfe_ss"] == b["mfe_ss"] and bool(np.abs(np.array(a["Epf"]) - np.array(b["Epf"])).max() < 1e-9)
     print("ragged", len(lens), "ok" if ok else "MISMATCH", flush=True)
