@@ -251,6 +251,28 @@ def test_fast_driver_solves_L200_on_gpu(eterna_targets):
     assert res["solved"] and res["stats"]["scored"] >= 64
 
 
+@pytest.mark.gpu
+def test_fast_driver_long_target_strip_path_equals_general_path(eterna_targets):
+    """A 400-nt puzzle (BASELINE config 5's target) through the native driver: the folds take the strip kernels (several
+    workgroups per sequence); with "strips" off the general one-workgroup kernels.  Same seed -> the same records, because the
+    kernels' answers are the same (MFE strings and energies bit for bit, Epf to 1e-13)."""
+    from desirna_amd import engine as E
+    tg = eterna_targets["eteV1_53.txt"]
+    inp = SimpleNamespace(name="ete53", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    out = []
+    for strips in (1, 0):
+        eng = E.Engine(max_R=16, max_L=len(tg), device=0)
+        eng.set_option("strips", strips)
+        res = design.run_design_fast(inp, replicas=16, exchange=10, steps=3, seed=7, engine=eng)
+        out.append(res)
+        eng.close()
+    a, b = out
+    assert a["best"].sequence == b["best"].sequence and a["best"].mfe_ss == b["best"].mfe_ss
+    assert a["stats"]["scored"] == b["stats"]["scored"] and a["stats"]["acc_mc"] == b["stats"]["acc_mc"]
+    assert [(r["sequence"], r["mfe_ss"]) for r in a["simulation_data"]] == [(r["sequence"], r["mfe_ss"]) for r in b["simulation_data"]]
+
+
 # ---- alternative structures: snakes (reference utils/sequence_utils.py:143-388, :1081-1095)
 
 ALT_TARGET = "((((((.((((((((....))))).)).).))))))"
