@@ -82,6 +82,8 @@ def test_bad_character_flag(emu):
 def test_lds_kernels_random(emu, oracle, L, nt):
     rng = np.random.default_rng(300 + L)
     seqs = [_rand(rng, L), _rand(rng, L, "GC")]
+    if nt == -1024:
+        seqs = seqs[:1]                  # 1024 OS threads per workgroup: one sequence keeps the CPU suite short
     E, ss, st = emu.mfe(seqs, nt=nt)
     Ep, stp = emu.pf(seqs, nt=nt)
     assert not st.any() and not stp.any()
