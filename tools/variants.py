@@ -12,9 +12,10 @@ seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 procs = []
 for k, a in enumerate(sys.argv[1:]):
-    flags = [f for f in a.split() if f.startswith("-D")]
+    flags = [f for f in a.split() if f.startswith("-D") or f.startswith("--offload-arch") or f.startswith("-m")]
+    arch = [] if any(f.startswith("--offload-arch") for f in flags) else ["--offload-arch=gfx950"]
     out = os.path.join(ROOT, "gpurun_out", "libvar%d.so" % k)
-    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950"] + flags +
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC"] + arch + flags +
                                   ["-shared", "-o", out, os.path.join(ROOT, "desirna_amd/csrc/engine.hip")], stderr=subprocess.DEVNULL))
 for p in procs:
     p.wait()
