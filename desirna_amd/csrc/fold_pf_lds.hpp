@@ -18,13 +18,15 @@
 #ifndef DRNA_JOIN_MASK
 #define DRNA_JOIN_MASK 0xF     // finalize waves that join the sweep's work queue once their own step is done
 #endif
+#include <cstddef>
 #include "fold_pf.hpp"
 
 namespace drna {
 
 constexpr int PF_FAST_NMAX = 200;
-constexpr int PGSLOTS = 10;       // tower entries per pinned wave: 28 residues over 3 waves
-constexpr int PNG = 3;            // sweep waves pinned to one 64-tower block
+constexpr int PGSLOTS = 10;       // strip kernels (fold_pf_strip.hpp): tower entries per pinned wave, 28 residues over 3 waves
+constexpr int PNG = 3;            // strip kernels: sweep waves pinned to one 64-tower block
+constexpr int TSL = 14;           // tower entries per tower wave: loop sizes s = 4 + sigma + 2 q (q = 0..13, s <= 30)
 
 template <int NT>
 struct PfFastSmem {
@@ -32,13 +34,17 @@ struct PfFastSmem {
   static constexpr int RS = PF_FAST_NMAX + 2;
   static constexpr int NSLOT = 4 * WAVE;
   static constexpr int NL = PF_FAST_NMAX + 8;
-  double qbi[33 * RS];            // qb * expMismatchI(inner side) of the last 32 diagonals; row 32 stays zero
+  double qbi[32 * RS];            // qb * expMismatchI(inner side) of the last 32 diagonals.  Zero-initialised: rows of diagonals
+                                  // that do not exist yet (d' <= TURN or negative, wrapped) read as zero until their first tenant
+                                  // is written, which is after their last such read.  (A pitch of 2 KB would let a 16-bit add wrap
+                                  // the row for free, but then equal columns of all rows share a bank and the bulge items, whose
+                                  // lanes read one column in sixteen rows, run into 16-way conflicts: measured +0.08 ms.)
   double dring[4 * RS];           // D[i,j] = sum_k qm[i,k-1] qm1[k,j] of the last 4 diagonals
   double qm1row[2][RS];           // qm1 of the previous diagonal
   double urow[2][RS];             // U of the previous diagonal
   double hpw[PF_FAST_NMAX + 2];   // hairpin weight by loop size (scale folded in)
   double q5[PF_FAST_NMAX + 2];
-  double partG[2][PNG][NSLOT];    // tower sums, one slice per pinned wave
+  double partG[2][2][NSLOT];      // tower sums, one slice per parity of the loop size
   double partK[2][4][NSLOT];      // multiloop sums, one slice per split-point group
   double accE[2][NSLOT], accX[2][3][NSLOT];   // accX: one slice per group of fixed shapes
   // Boltzmann tables
@@ -50,13 +56,11 @@ struct PfFastSmem {
   double eW[128];                 // E items: size weight (x scale) of shape slot x (0..63 bulges, 64..127 1xn loops; padding 0)
   int eshape[128];                // s = u1+u2 | u1 << 8 of the slot
   double xc[8];                   // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items)
-  double tw_as[32], tw_W[32];     // by total size s of a generic loop: asymmetry-independent factors (see pf_prepare_tables)
-  double tw_d[2][32][3];          // per residue: asymmetry factor, keep factor (0 forgets the previous tenant), size factor
-  int tw_i[2][32][2];             // per residue: byte offsets A, B into qbi
+  double twc[32][2];              // by total size s of a generic loop: {eninio[s - 4], interior[s] scale[s + 2] (0 below s = 6)}
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int qhead[2];                   // work-queue head of the diagonal's floating items
-  unsigned char info[33 * RS];    // row 32 stays zero, like qbi's
+  unsigned char info[32 * RS];    // zero-initialised like qbi
   unsigned char S[PF_FAST_NMAX + 4];
   int flag;
 };
@@ -136,6 +140,60 @@ __device__ __forceinline__ double pf_tower_step(const SM& sm, double (&G)[PGSLOT
   return lo + hi;
 }
 
+
+// ---- tower step of pf_lds_kernel (round 3): entries indexed by the LOOP SIZE s, not by the inner diagonal.
+// G_s(i,j) = G_{s-2}(i+1,j-1) + (X[d'][i+3] + X[d'][i+s-1]) eninio[s-4] with d' = d - 2 - s, and the step of a tower from
+// diagonal d-2 to d moves every sum from size s-2 to s: in descending order of s that is G[q] <- G[q-1] + ..., a shift that
+// the FMA's separate destination register does for free.  Everything per entry is then a compile-time constant except the
+// ring row (d - 2 - s) & 31: three VALU for the address, one ds_read2_b64 with immediate column offsets, one broadcast read
+// of the entry's two constants, one add and two FMAs (the table-driven form this replaces: eight v_readlane, two adds and
+// four fp64 operations per entry, plus a table a finalize wave rebuilt every diagonal).  A wave owns the sizes of one parity
+// (s and s-2 must live in the same registers); rows of diagonals that do not exist yet read as zero (see PfFastSmem::qbi).
+// d = a * b + c with a destination of its own (the compiler prefers v_fmac + a copy)
+__device__ __forceinline__ double fma3_f64(double a, double b, double c) {
+#ifdef DRNA_EMU
+  return a * b + c;
+#else
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#endif
+}
+
+template <class SM, int SIG, int Q0, int Q1>
+__device__ __forceinline__ void pf_tower2_part(const SM& sm, double (&G)[TSL], int dv, int i8, int cbase, double& acc) {
+  const char* ring = reinterpret_cast<const char*>(sm.qbi);
+  double a[Q1 - Q0], b[Q1 - Q0];
+  f64x2 c[Q1 - Q0];
+#pragma unroll
+  for (int q = Q1 - 1; q >= Q0; q--) {
+    const int s = 4 + SIG + 2 * q;
+    if (s > 30) continue;
+    const int va = ((dv - s) & 31) * (SM::RS * 8) + i8;        // dv = d + 30 in a VGPR: row (d - 2 - s) & 31
+    a[q - Q0] = *reinterpret_cast<const double*>(ring + va + 24);
+    b[q - Q0] = s == 4 ? 0.0 : *reinterpret_cast<const double*>(ring + va + (s - 1) * 8);     // s = 4 has the single shape (2,2)
+    c[q - Q0] = *reinterpret_cast<const f64x2*>(ring + cbase + s * 16);                       // the entry's two constants (same address in every lane)
+  }
+#pragma unroll
+  for (int q = Q1 - 1; q >= Q0; q--) {
+    const int s = 4 + SIG + 2 * q;
+    if (s > 30) continue;
+    G[q] = q > 0 ? fma3_f64(a[q - Q0] + b[q - Q0], c[q - Q0].x, G[q - 1]) : (a[q - Q0] + b[q - Q0]) * c[q - Q0].x;
+    acc += G[q] * c[q - Q0].y;
+  }
+}
+
+template <class SM, int SIG>
+__device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL], int dv, int i8) {
+  // byte offset of the constants from the ring's start, kept out of the compiler's sight (a literal address costs a v_mov per read)
+  const int cbase = as_vector((int)(reinterpret_cast<const char*>(&sm.twc[0][0]) - reinterpret_cast<const char*>(sm.qbi)));
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  pf_tower2_part<SM, SIG, 9, 14>(sm, G, dv, i8, cbase, acc0);     // descending: the upper entries read their predecessors first
+  pf_tower2_part<SM, SIG, 4, 9>(sm, G, dv, i8, cbase, acc1);
+  pf_tower2_part<SM, SIG, 0, 4>(sm, G, dv, i8, cbase, acc2);
+  return (acc0 + acc1) + acc2;
+}
+
 // Diagnostic builds only (-DDRNA_SKIP=mask, tools/phase_cost.py): leave out a sweep phase to read its marginal cost
 // from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = cell finalize, 32 = table / pairable-list
 // preparation, 64 = exterior column.
@@ -152,7 +210,7 @@ __device__ __forceinline__ double pf_tower_step(const SM& sm, double (&G)[PGSLOT
 
 template <int NT>
 __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
-  __shared__ PfFastSmem<NT> sm;
+  __shared__ PfFastSmem<NT> sm;              // the kernel's only LDS object: offset 0
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
@@ -212,13 +270,13 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     sm.xc[2] = A.scale[4]; sm.xc[3] = A.scale[5]; sm.xc[4] = A.scale[6];
   }
   for (int k = tid; k < 32; k += NT) {
-    sm.tw_as[k] = k >= 4 && k <= 30 ? T.eninio[k - 4] : 0.0;
-    sm.tw_W[k] = k >= 6 && k <= 30 ? T.interior[k] * A.scale[k + 2] : 0.0;
+    sm.twc[k][0] = k >= 4 && k <= 30 ? T.eninio[k - 4] : 0.0;
+    sm.twc[k][1] = k >= 6 && k <= 30 ? T.interior[k] * A.scale[k + 2] : 0.0;
   }
   for (int k = tid; k < 4 * RS; k += NT) sm.dring[k] = 0.0;
-  for (int k = tid; k < RS; k += NT) { sm.qbi[32 * RS + k] = 0.0; sm.info[32 * RS + k] = 0; }
+  for (int k = tid; k < 32 * RS; k += NT) { sm.qbi[k] = 0.0; sm.info[k] = 0; }
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
-  for (int k = tid; k < 2 * PNG * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
+  for (int k = tid; k < 2 * 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accE[0][0])[k] = 0.0;
   for (int k = tid; k < 6 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accX[0][0][0])[k] = 0.0;
@@ -263,14 +321,24 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   const int off0 = (NB * WAVE - n) / 2;
   const int NA = NW - NB;                  // sweep waves
   const int aw = wave - NB;                // index among the sweep waves (< 0: finalize wave)
-  const int my_tb = aw >= 0 ? aw / PNG : NB, my_g = aw >= 0 ? aw - my_tb * PNG : 0;
-  const bool pinned = aw >= 0 && my_tb < NB;
-  const int w_tab = NB > 1 ? 1 : 0, w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
+  // Tower roles.  Generic loops exist from diagonal 10 on, where n - 10 cells are left: NBT = ceil((n - 10) / 64) blocks of 64 tower
+  // slots starting at slot T0 cover them for the rest of the fill (the slot range only shrinks).  1024 threads: a block gets
+  // four waves, parity of the loop size x parity of the diagonal -- such a wave works every other step and carries 14 sums;
+  // n = 200: three blocks, twelve roles, every sweep wave has one.  Smaller workgroups (CPU emulation of n <= 64): two waves
+  // per block, both diagonal parities each.
+  constexpr bool TWO_PAR = NT < 1024;
+  const int nT = n - 10, NBT = nT > 0 ? (nT + WAVE - 1) / WAVE : 0;
+  const int T0 = max(0, off0 + 5 - (NBT * WAVE - nT) / 2);
+  int my_tb = -1, my_sig = 0, my_pm = 0;             // block, parity of s, mask of the diagonal parities taken (0: no tower role)
+  if (aw >= 0) {
+    if (TWO_PAR) { if (aw < 2 * NBT) { my_tb = aw >> 1; my_sig = aw & 1; my_pm = 3; } }
+    else if (aw < 4 * NBT) { my_tb = aw >> 2; const int x = (aw + my_tb) & 3; my_sig = x & 1; my_pm = 1 << (x >> 1); }
+  }
+  const int w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
 
   if (aw < 0) {
     const int d = TURN + 1;
     if (d < n) {
-      pf_prepare_tables(sm, d, tid);
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
       if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
@@ -372,7 +440,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int dp = d - 2 - (sh[k] & 255);                // diagonal of the inner pair
-            off[k] = (dp > TURN ? (dp & 31) * RS + 1 + (sh[k] >> 8) : 32 * RS) + i0;
+            off[k] = (dp & 31) * RS + 1 + (sh[k] >> 8) + i0;             // rows of diagonals <= TURN read as zero
           }
 #pragma unroll
           for (int k = 0; k < 4; k++) { w[k] = sm.qbi[off[k]]; f[k] = sm.info[off[k]]; }
@@ -445,10 +513,10 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
         if (!(DRNA_SKIP & 16) && i >= 1 && i <= ncell) {
-          const double aG = (sm.partG[par][0][tid] + sm.partG[par][1][tid]) + sm.partG[par][2][tid];
+          const double aG = sm.partG[par][0][tid] + sm.partG[par][1][tid];
           const double aK = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
           const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
-          sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0; sm.partG[par][2][tid] = 0.0;
+          sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0;
           sm.partK[par][0][tid] = 0.0; sm.partK[par][1][tid] = 0.0; sm.partK[par][2][tid] = 0.0; sm.partK[par][3][tid] = 0.0;
           sm.accE[par][tid] = 0.0; sm.accX[par][0][tid] = 0.0; sm.accX[par][1][tid] = 0.0; sm.accX[par][2][tid] = 0.0;
           const int j = i + d;
@@ -505,7 +573,6 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       // pairable list of diagonal k+1, exterior column j = k-3 (its cells were stored in step <= k-3 and drained by
       // that step's barrier)
       if (!(DRNA_SKIP & 32) && k + 1 < n) {
-        if (wave == w_tab) pf_prepare_tables(sm, k + 1, lane);
         if (wave == w_pl) {
           const int32_t* row = PL + (k + 1) * ld;
           const int cnt = row[ld - 1];
@@ -530,22 +597,28 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     }
   } else {
     // ================= sweep waves: diagonal d = k at step k
-    double GE[PGSLOTS], GO[PGSLOTS];
+    double GE[TSL], GO[TSL];
 #pragma unroll
-    for (int q = 0; q < PGSLOTS; q++) { GE[q] = 0.0; GO[q] = 0.0; }
+    for (int q = 0; q < TSL; q++) { GE[q] = 0.0; if (TWO_PAR) GO[q] = 0.0; }
     for (int k = TURN + 1; k <= n; k++) {
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int lo = sh + off0, hi = ncell + sh + off0 - 1;
-        const int tb_lo = lo >> 6, tb_hi = hi >> 6;
-        const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
         // ---- T: tower step
-        if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
-          int i = my_tb * WAVE + lane + 1 - sh - off0;
+        if (!(DRNA_SKIP & 1) && ((my_pm >> par) & 1) && d >= 10) {
+          const int blo = T0 + my_tb * WAVE;                        // the block's slots blo .. blo + 63; the diagonal's cells lo .. hi
+          int i = blo + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const double accG = par ? pf_tower_step(sm, GO, par, i * 8, my_g, lane) : pf_tower_step(sm, GE, par, i * 8, my_g, lane);
-          sm.partG[par][my_g][my_tb * WAVE + lane] = accG;
+          const int dv = as_vector(d + 30), i8 = i * 8;
+          if (blo <= hi && blo + WAVE - 1 >= lo) {
+            double accG = 0.0;
+            if constexpr (TWO_PAR) {
+              if (par) accG = my_sig ? pf_tower2_step<PfFastSmem<NT>, 1>(sm, GO, dv, i8) : pf_tower2_step<PfFastSmem<NT>, 0>(sm, GO, dv, i8);
+            }
+            if (!TWO_PAR || !par) accG = my_sig ? pf_tower2_step<PfFastSmem<NT>, 1>(sm, GE, dv, i8) : pf_tower2_step<PfFastSmem<NT>, 0>(sm, GE, dv, i8);
+            sm.partG[par][my_sig][T0 + my_tb * WAVE + lane] = accG;
+          }
         }
         STAMP(0);
         run_items(d);
