@@ -3,6 +3,7 @@
 for R=64 replicas x L=200 per GPU (BASELINE.json configs[2]) on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N ...          (N > 1 without WORLD_SIZE in the environment: launches the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of R sequences resident in HBM: what the reference
@@ -12,9 +13,10 @@ exchange is the all-gather of the R x N scoring-function values before a replica
 (reference utils/replica_exchange_monte_carlo.py:113-173), issued every --exchange-every steps as in
 the reference's e=100 Monte-Carlo iterations per exchange step, and once after the last step.
 
-Prints ONE JSON line (rank 0).  'roofline' names the tightest of three bounds of the dominant kernel (HBM bytes, LDS-array
-cycles, the 2n-step dependency chain; see roofline_block); 'cpu_baseline' times the CPU oracle (a port of the ViennaRNA
-recursions; ViennaRNA itself is not on this box) on the same workload and its results are compared with the GPU's.
+Prints ONE JSON line (rank 0).  'roofline' prices the dominant kernel against the HARDWARE peaks only (HBM bytes, LDS-array
+cycles, VALU issue at the SIMD-32 pipe rate) and reports the kernel's own finalize-only floor separately (see
+roofline_block); 'cpu_baseline' times the CPU oracle (a port of the ViennaRNA recursions; ViennaRNA itself is not on this
+box) on the same workload and its results are compared with the GPU's.
 """
 import argparse
 import csv
@@ -96,9 +98,14 @@ def cpu_baseline(seqs, target, budget_s=25.0):
     from desirna_amd import params
     from oracle import pyoracle
     pyoracle.build()
-    orc = pyoracle.Oracle(params.load_blob())
+    native = pyoracle.build_native()                 # -march=native on this host; the shipped build is x86-64-v3
+    try:
+        orc = pyoracle.Oracle(params.load_blob(), lib=native)
+    except OSError:
+        native = None
+        orc = pyoracle.Oracle(params.load_blob())
     cores, quota = usable_cores()
-    flags = pyoracle.FLAG_PF | pyoracle.FLAG_MFE
+    flags = pyoracle.FLAG_PF | pyoracle.FLAG_MFE | pyoracle.FLAG_PIN
     table = []
     ref = None
     tstart = time.perf_counter()
@@ -124,7 +131,14 @@ def cpu_baseline(seqs, target, budget_s=25.0):
     # the oracle's answers for the benchmark batch itself (parity check of the timed GPU path)
     ref = orc.score_batch(list(seqs), [target], flags, threads=cores)
     single, allc = table[0]["folds_per_s"], table[-1]["folds_per_s"]
+    hw = os.cpu_count() or cores
     return {"value": allc, "unit": "replica-folds/s", "cores": cores, "kind": "port",
+            "build": "gcc -O3 -march=native (built on this host)" if native else "gcc -O3 -march=x86-64-v3 (shipped build)",
+            # the reference starts one process per replica (utils/replica_exchange_monte_carlo.py:233-271): on a host whose
+            # hardware threads are all available to it, R replicas fold on min(R, hardware threads) cores at once.  NOT
+            # measured (this lease's cgroup allows `cores` of them): single-core rate x that count, stated as an extrapolation
+            "reference_style_R_processes": {"value": single * min(len(seqs), hw), "processes": min(len(seqs), hw),
+                                            "host_hardware_threads": hw, "kind": "extrapolation: single_core_value x processes"},
             "sample": "%d x L=%d sequences (the benchmark batch tiled to 8 folds per thread), best of 3 after one warm-up, %d "
                       "threads = usable cores (affinity %d, cgroup quota %s, os.cpu_count %d), thread t bound to the t-th "
                       "CPU of the affinity mask; MFE fill+traceback + PF + eval each"
@@ -133,11 +147,15 @@ def cpu_baseline(seqs, target, budget_s=25.0):
 
 
 def roofline_block(dom, dom_ms, L, R, tk):
-    """Three candidate bounds for the dominant fold kernel, each a fraction that cannot exceed 1; the largest is named as
-    `bound`.  hbm: measured HBM bytes per launch / kernel time / 8 TB/s.  lds: LDS-array busy cycles per CU / kernel cycles.
-    chain: the 2n-step dependency chain -- time of the same kernel with every sweep phase left out (finalize + barrier
-    only, the floor no amount of bandwidth removes) / kernel time.  Counter inputs come from profiles/ (rocprofv3 PMC
-    passes and the floor build of the SAME source, tools/gpu_round2.sh); kernel time is measured live here."""
+    """The dominant fold kernel against HARDWARE peaks only -- `bound` is the largest of
+         hbm : measured HBM bytes per launch (PMC: (2 FETCH_SIZE + WRITE_SIZE) KB) / kernel time / 8 TB/s
+         lds : LDS-array busy cycles per CU (SQ_LDS_IDX_ACTIVE / workgroups) / kernel cycles at 2.4 GHz
+         valu: VALU wave-instructions per SIMD (SQ_ACTIVE_INST_VALU / (4 workgroups)) x 2 cycles (SIMD-32 pipe rate,
+               MI355X_MICROARCH.md 'Wave scheduling') / kernel cycles; the 4-cycle figure (what ONE wave alone sustains) is
+               given beside it as frac_wave_issue_4cycle
+    and `own_floor` = time of the same kernel with every sweep phase left out (finalize + barrier only) / kernel time, a
+    property of this implementation, not of the hardware, reported separately.  Counter inputs come from profiles/
+    (rocprofv3 PMC passes and the floor build of the SAME source, tools/gpu_round2.sh); kernel time is measured live here."""
     src = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     mfe_b, pf_b = b_alg_bytes(L)
     stream = (pf_b if dom == "pf" else mfe_b) * R
@@ -155,30 +173,69 @@ def roofline_block(dom, dom_ms, L, R, tk):
     t = dom_ms * 1e-3
     if k.get("kernel"):
         out["kernel"] = k["kernel"].replace("void drna::", "").split("(")[0]
+    clk = k.get("clock_hz", 2.4e9)
     bounds = {}
     if k.get("hbm_bytes_per_launch"):
         a = k["hbm_bytes_per_launch"] / t / 1e9
         bounds["hbm"] = {"achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0}
         out["traffic"] = k["hbm_bytes_per_launch"]
     if k.get("lds_busy_cycles_per_cu"):
-        clk = k.get("clock_hz", 2.4e9)
         a = k["lds_busy_cycles_per_cu"] / t
         bounds["lds"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G LDS-array cycles/s per CU", "frac": a / clk,
                          "bank_conflict_share": k.get("lds_bank_conflict_share")}
     if k.get("valu_busy_cycles_per_simd"):
-        clk = k.get("clock_hz", 2.4e9)
-        a = k["valu_busy_cycles_per_simd"] / t
-        bounds["valu"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G VALU issue cycles/s per SIMD", "frac": a / clk}
-    if k.get("floor_ms"):
-        steps = L - 4
-        bounds["chain"] = {"achieved": steps / t, "peak": steps / (k["floor_ms"] * 1e-3), "unit": "diagonal steps/s per workgroup",
-                           "frac": k["floor_ms"] / dom_ms, "floor_ms": k["floor_ms"]}
+        # the inputs file prices an instruction at 4 cycles (valu_cycles_per_count); the pipe itself takes 2
+        insts = k["valu_busy_cycles_per_simd"] / inp.get("valu_cycles_per_count", 4.0)
+        a = insts * 2.0 / t
+        bounds["valu"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G VALU pipe cycles/s per SIMD (2 per wave64 instruction)",
+                          "frac": a / clk, "frac_wave_issue_4cycle": insts * 4.0 / t / clk, "wave_instructions_per_simd": insts}
     if bounds:
         name = max(bounds, key=lambda b: bounds[b]["frac"])
         out.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
                     "unit": bounds[name]["unit"], "frac": bounds[name]["frac"], "bounds": bounds,
+                    "formulas": {"hbm": "(2*FETCH_SIZE + WRITE_SIZE)*1024 B / kernel_s / 8e12",
+                                 "lds": "SQ_LDS_IDX_ACTIVE / workgroups / (kernel_s * 2.4e9)",
+                                 "valu": "SQ_ACTIVE_INST_VALU / (4*workgroups) * 2 / (kernel_s * 2.4e9)"},
                     "inputs": "profiles/roofline_inputs.json (%s)" % inp.get("source", "?")})
+    if k.get("floor_ms"):
+        out["own_floor"] = {"floor_ms": k["floor_ms"], "frac": k["floor_ms"] / dom_ms,
+                            "note": "same kernel, every sweep phase left out (finalize + barrier only): this implementation's "
+                                    "dependency chain, not a hardware peak"}
+    out["workgroups"] = k.get("workgroups")
     return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks from here, one process
+    per GPU, as torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's JSON
+    line and return non-zero if any rank failed.  This parent imports neither torch nor the engine and never touches the GPU;
+    the ranks are plain child processes (nothing is exec'ed over an initialised process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    deadline = time.time() + 1800
+    for p_ in procs:
+        try:
+            rcs.append(p_.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
 
 
 def main():
@@ -192,10 +249,22 @@ def main():
     ap.add_argument("--seqs", choices=["uniform", "design"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))        # before torch / HIP are touched in this process
+    if os.environ.get("DRNA_BENCH_ECHO_RANK"):           # tests/test_host_cpu.py: what a rank was started with, no GPU needed
+        me = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        me["gpus"] = args.gpus
+        with open(os.path.join(os.environ["DRNA_BENCH_ECHO_RANK"], "rank%s.json" % me["RANK"]), "w") as fh:
+            json.dump(me, fh)
+        if me["RANK"] in (None, "0"):
+            print(json.dumps(me))
+        raise SystemExit(3 if os.environ.get("DRNA_BENCH_ECHO_FAIL") == me["RANK"] else 0)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: running %d ranks\n" % (args.gpus, world, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
@@ -207,6 +276,9 @@ def main():
     backend = os.environ.get("DRNA_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (DRNA_BENCH_BACKEND=gloo rehearses the "
+                         "launch on fewer)" % (world, world, torch.cuda.device_count()))
     if world > 1:
         if backend == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -286,9 +358,15 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in tk.items()},
             "roofline": roofline_block(dom, tk[dom], L, R, tk),
         }
+        hb = (out["roofline"].get("bounds") or {}).get("hbm")
+        out["achieved_hbm_GB_s"] = hb["achieved"] if hb else None          # BASELINE metric: "HBM GB/s vs peak" (8000)
+        out["achieved_hbm_frac_of_peak"] = hb["frac"] if hb else None
+        out["sync_fallbacks"] = eng.get_option("sync_fallbacks")          # calls redone with one workgroup per fold (lost partner)
+        out["cus_occupied"] = {"workgroups": eng.get_option("last_workgroups"), "compute_units": eng.info()["compute_units"]}
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would idle at the barrier
             out["cpu_baseline"], ref = cpu_baseline(seqs, target)
             out["speedup_vs_cpu_usable_cores"] = out["value"] / world / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_reference_style_R_processes"] = out["value"] / world / out["cpu_baseline"]["reference_style_R_processes"]["value"]
             # what the timed steps left in the device buffers against the oracle's answers for the same batch:
             # MFE energy, MFE structure and E(target) bit for bit, Epf to 1e-9 kcal/mol
             r_Epf, r_Emfe, r_ss, r_Ed = ref

@@ -90,14 +90,16 @@ struct drna_engine {
   bool dual = true;               // DRNA_DUAL=0 turns them off
   bool dual_force = false;        // option "dual" = 2: also beside a partition function (tests, diagnostics)
   int dual_cap = 0;               // sequences the exchange buffers hold
-  int dual_epoch = 0;             // grows by one per launch; flags are never reset (fold_common.hpp, DualLink)
+  int dual_epoch = 0;             // grows by one per launch; flags and epoch go back to zero at DUAL_EPOCH_RESET (fold_common.hpp, DualLink)
   int* d_dflags = nullptr;        // [2 kernels][dual_cap][64]
   int32_t *d_xs = nullptr, *d_xa_mfe = nullptr, *d_xb_mfe = nullptr;
   // strip kernels (fold_pf_strip.hpp: 200 < n <= 2046, several workgroups per sequence): one flag line per (sequence, strip)
   int strips = 1;                 // 0 off (general kernel), 1 for n > 200, 2 also for 64 < n <= 200 (two strips; diagnostics)
-  int strip_epoch = 0;            // grows by one per call; flags are never reset
+  int strip_epoch = 0;            // grows by one per launch; flags and epoch go back to zero at STRIP_EPOCH_RESET
+  int flag_resets = 0;            // times the hand-over flags were zeroed because an epoch neared the compare range
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
   int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
+  int last_wgs = 0;               // fold workgroups of the last drna_score_batch call (partition function + MFE kernels, resident side by side)
   int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
   bool in_fallback = false;
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
@@ -128,6 +130,9 @@ static hipError_t upload(T** dst, const T* src, size_t count) {
 }
 
 static size_t mfe_ws_stride(int ld) { return (size_t)5 * ld * ld; }                       // int32
+// hand-over flags hold (epoch << 12 | diagonal) for the strips and ((epoch * 8 + round) << 10 | diagonal) for the two-workgroup
+// kernel, compared wrap-safe: valid while live values are less than 2^31 apart, i.e. 2^19 (2^18) epochs.  Reset at a quarter of that.
+constexpr int STRIP_EPOCH_RESET = 1 << 17, DUAL_EPOCH_RESET = 1 << 16;
 
 // strips of a sequence of length n (0 = not a strip case): widest strip STRIP_WMAX columns; the exchange records of the
 // S - 1 strip boundaries must fit tables 0 and 1 of the sequence's workspace
@@ -156,6 +161,16 @@ static int strip_flags(drna_engine* e, bool mfe) {
       HIP_TRY(hipDeviceSynchronize());
     }
   }
+  // Flag compares are wrap-safe over HALF the 32-bit range only (2^19 epochs of 4096 values): a slot that was never written, or
+  // not written for 2^19 launches (the MFE half after a long partition-function-only phase, a larger batch than seen before,
+  // more strips than before), would then read as already published.  Every stream is idle here, so long before that point the
+  // flags go back to zero and the epochs start over.
+  if (e->strip_epoch >= STRIP_EPOCH_RESET) {
+    HIP_TRY(hipMemset(e->d_sflags, 0, (size_t)2 * e->max_R * STRIP_MAXS * 32 * sizeof(int)));
+    HIP_TRY(hipDeviceSynchronize());
+    e->strip_epoch = 0;
+    e->flag_resets++;
+  }
   if (mfe && !e->d_srec) {
     const int smax = std::min(STRIP_MAXS, strip_count(std::min(e->max_L, STRIP_NMAX), STRIP_WMAX) + 1);
     e->srec_stride = (long long)std::max(smax, 2) * (e->max_L + 2) * MSTRIP_REC;
@@ -164,7 +179,7 @@ static int strip_flags(drna_engine* e, bool mfe) {
   return DRNA_OK;
 }
 static int next_strip_epoch(drna_engine* e) {
-  e->strip_epoch = (int)((unsigned)e->strip_epoch + 1u);          // never reset: flag compares are wrap-safe
+  e->strip_epoch = (int)((unsigned)e->strip_epoch + 1u);          // reset by strip_flags() long before the compares' half range
   return (int)((unsigned)e->strip_epoch << 12);
 }
 
@@ -299,12 +314,15 @@ extern "C" void drna_destroy(drna_engine* e) {
   delete e;
 }
 
+extern "C" int drna_abi_version(void) { return DRNA_ABI_VERSION; }
+
 extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
+  if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
 }
@@ -323,6 +341,9 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!strcmp(name, "dual")) { *value = e->dual ? (e->dual_force ? 2 : 1) : 0; return DRNA_OK; }
   if (!strcmp(name, "strips")) { *value = e->strips; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
+  if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
+  if (!strcmp(name, "flag_resets")) { *value = e->flag_resets; return DRNA_OK; }
+  if (!strcmp(name, "debug_epoch")) { *value = e->strip_epoch > e->dual_epoch ? e->strip_epoch : e->dual_epoch; return DRNA_OK; }
   return DRNA_ERR_ARG;
 }
 
@@ -411,12 +432,19 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       e->dual_cap = R;
       e->dual_epoch = 0;
     }
-    e->dual_epoch = (int)((unsigned)e->dual_epoch + 1u);           // never reset: flag compares are wrap-safe
+    if (e->dual_epoch >= DUAL_EPOCH_RESET) {                       // same reasoning as in strip_flags(): 8192 flag values per epoch
+      HIP_TRY(hipMemset(e->d_dflags, 0, (size_t)2 * e->dual_cap * 64 * sizeof(int)));
+      HIP_TRY(hipDeviceSynchronize());
+      e->dual_epoch = 0;
+      e->flag_resets++;
+    }
+    e->dual_epoch = (int)((unsigned)e->dual_epoch + 1u);
   }
   // longer sequences (and, as an option, short ones in small batches): the partition function by strips of columns, one
   // workgroup each (fold_pf_strip.hpp)
   const int pf_strips = want_pf ? strips_for(e, L, ld) : 0;
   const int mfe_strips = want_mfe ? strips_for(e, L, ld) : 0;
+  e->last_wgs = 0;
   if (pf_strips || mfe_strips) { const int rc = strip_flags(e, mfe_strips != 0); if (rc != DRNA_OK) return rc; }
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
@@ -428,6 +456,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
+    e->last_wgs += pf_strips ? R * pf_strips : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
     else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
@@ -445,6 +474,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
     a.Emfe = d_Emfe; a.ss = d_mfe_ss; a.status = e->d_status;
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+    e->last_wgs += use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R;
     if (use_dual) {
       DualLink lk;
       lk.flagA = e->d_dflags; lk.flagB = e->d_dflags;

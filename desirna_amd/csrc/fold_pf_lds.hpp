@@ -392,7 +392,12 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
         int vA = (tt * ld + i) * 8;
         int vC = (int)tab * 8 + ((d - tt - 1) * ld + i + tt + 1) * 8;          // operand of tt (never negative)
-        for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
+#ifdef DRNA_KFAKE
+        const int tmax = min(d - TURN - 2, TURN + DRNA_KFAKE);                  // timing experiments only: the first DRNA_KFAKE terms
+#else
+        const int tmax = d - TURN - 2;
+#endif
+        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
           const int vCl = vC - 3 * cstep;                                       // operand of tt + 3 KG: in range here
           const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vCl, 3 * cstep);
           const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vCl, 2 * cstep);
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
           p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
         }
-        for (; tt <= d - TURN - 2; tt += KG) {
+        for (; tt <= tmax; tt += KG) {
           const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 0);
           p0 += a0.x * c0.x; q0 += a0.y * c0.y;
           vA += astep; vC -= cstep;
@@ -586,7 +591,12 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
       if (!(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
       STAMP(4);
       if (!(DRNA_SKIP & 128) && k < n && ((DRNA_JOIN_MASK >> wave) & 1)) run_items(k);          // help the sweep of diagonal k
+#ifdef DRNA_PF_LDSBAR
+      stores_in_flight<DRNA_PF_LDSBAR>();
+      lds_barrier();
+#else
       __syncthreads();
+#endif
       STAMP(3);
 #ifdef DRNA_STAMPS
       if (blockIdx.x == 0 && tid == 0) dbg[256 + k] = st_acc[4];
@@ -624,7 +634,11 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         run_items(d);
         STAMP(6);
       }
+#ifdef DRNA_PF_LDSBAR
+      lds_barrier();
+#else
       __syncthreads();
+#endif
       STAMP(3);
 #ifdef DRNA_STAMPS
       if (blockIdx.x == 0 && aw == 0 && lane == 0) dbg[512 + k] = st_last;

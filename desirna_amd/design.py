@@ -394,6 +394,9 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     replays the swaps on the whole ladder.  Results do not depend on the sharding (streams are seeded by the GLOBAL
     replica index and the kernels' results do not depend on the batch composition)."""
     from . import engine as _engine
+    if stop_when_solved and num_results is not None and not keep_records:
+        raise ValueError("the -sws rule with num_results ranks the recorded sequences: it needs keep_records=True "
+                         "(without records the stop test could never fire and the run would only end at its step / time limit)")
     prob = DesignProblem(input_file.sec_struct, input_file.seq_restr, input_file.alt_sec_structs)
     if prob.two_strands:
         raise NotImplementedError("two-strand inputs run through run_design (the native batched proposer is one-strand)")

@@ -25,7 +25,9 @@ EXPORTS = ("drna_create", "drna_destroy", "drna_last_error", "drna_set_targets",
            "drna_score_batch_device", "drna_last_timing", "drna_info", "drna_simscore_batch", "drna_propose_batch",
            "drna_metropolis_batch", "drna_ensemble_defect_batch", "drna_ensemble_defect_batch_device",
            "drna_last_edef_timing", "drna_propose_batch_alt", "drna_set_targets_ragged", "drna_score_ragged", "drna_cofold_batch", "drna_mc_run", "drna_subopt_energy_batch",
-           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums", "drna_debug_strip_clocks", "drna_get_option")
+           "drna_subopt_structs_batch", "drna_rng_seed", "drna_rng_random", "drna_set_option", "drna_timing_sums", "drna_debug_strip_clocks", "drna_get_option", "drna_abi_version")
+
+ABI_VERSION = 3        # DRNA_ABI_VERSION this binding was written against (include/desirna_amd.h)
 
 RNG_WORDS = 625        # DRNA_RNG_WORDS: uint32 words of one replica's MT19937 stream
 
@@ -57,6 +59,10 @@ def load_library(path=None):
     L.drna_score_batch.argtypes = [vp, ci, ci, C.c_char_p, u32, vp, vp, vp, vp]
     L.drna_score_batch_device.restype = ci
     L.drna_score_batch_device.argtypes = [vp, ci, ci, vp, u32, vp, vp, vp, vp]
+    L.drna_abi_version.restype = ci
+    L.drna_abi_version.argtypes = []
+    if L.drna_abi_version() != ABI_VERSION:
+        raise EngineError(-1, "library ABI version %d, this binding expects %d: rebuild desirna_amd/csrc" % (L.drna_abi_version(), ABI_VERSION))
     L.drna_last_timing.restype = ci
     L.drna_last_timing.argtypes = [vp, vp]
     L.drna_info.restype = ci
@@ -102,6 +108,16 @@ def load_library(path=None):
     return L
 
 
+_LIVE = None          # weak set of open engines, _CLOSED_FALLBACKS: the counters of the closed ones (sync_fallbacks_total)
+_CLOSED_FALLBACKS = 0
+
+
+def sync_fallbacks_total():
+    """Calls of this process, over all engines, in which a fold by several workgroups lost a partner and was redone with one
+    workgroup per fold (``drna_get_option("sync_fallbacks")``): 0 on a healthy box; the GPU test suite asserts it."""
+    return _CLOSED_FALLBACKS + sum(e.get_option("sync_fallbacks") for e in list(_LIVE or ()) if e._h and e._h.value)
+
+
 class Engine:
     """One engine per GPU (``RNA.params_load`` + all ``RNA.fold_compound`` allocations, done once)."""
 
@@ -116,6 +132,11 @@ class Engine:
         self.max_R, self.max_L, self.device = int(max_R), int(max_L), int(device)
         self.n_targets = 0
         self.L = None
+        global _LIVE
+        if _LIVE is None:
+            import weakref
+            _LIVE = weakref.WeakSet()
+        _LIVE.add(self)
 
     def set_option(self, name, value):
         """Engine option (``drna_set_option``): ``"dual"`` = fold small batches with two workgroups per sequence (default on)."""
@@ -129,6 +150,11 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            global _CLOSED_FALLBACKS
+            try:
+                _CLOSED_FALLBACKS += self.get_option("sync_fallbacks")
+            except Exception:
+                pass
             self._L.drna_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -257,6 +283,7 @@ class Engine:
             pk = prob._native_pack
         am, partner, snake_of, off, nodes, nst, chars = pk
         R, L = state["seqs"].shape
+        assert rng_state.dtype == np.uint32 and rng_state.shape == (R, RNG_WORDS) and rng_state.flags.c_contiguous
         ids = np.array([self.TERM_IDS[n] for n, _ in scoring_f], dtype=np.int32)
         ws = np.array([w for _, w in scoring_f], dtype=np.float64)
         sh = np.ascontiguousarray(shelf_index, dtype=np.int32)
@@ -436,6 +463,7 @@ class HostKernels:
         sm = np.ascontiguousarray(score_m, dtype=np.float64)
         tt = np.ascontiguousarray(temps, dtype=np.float64)
         R = so.shape[0]
+        assert rng_state.dtype == np.uint32 and rng_state.shape == (R, RNG_WORDS) and rng_state.flags.c_contiguous
         acc = np.zeros(R, dtype=np.uint8)
         bet = np.zeros(R, dtype=np.uint8)
         rc = self._L.drna_metropolis_batch(R, so.ctypes.data, sm.ctypes.data, tt.ctypes.data, float(L_const),

@@ -59,7 +59,7 @@ def best_fasta_text(simulation_data, infile, now, num_results=10):
 def sort_and_filter(simulation_data, num_results=10, oligo_state="none", subopt="off", sec_struct=None):
     """Unique sequences (last occurrence wins), best first (reference ``sort_and_filter_simulation_data``,
     ``utils/stats_inputs_outputs.py:384-419``): lowest 1-MCC, then by branch -- ``-oa on``: scoring function, Ed-Epf, Epf;
-    ``-d on``: oligomer fraction (ascending for two different strands, descending for two equal ones), Ed-Epf, Epf;
+    ``-d on``: oligomer fraction (LARGEST first for two different strands, smallest first for two equal ones), Ed-Epf, Epf;
     ``-nd on``: Ed-Epf, then the LARGEST Esubopt-Epf; plain: Ed-Epf, Epf, scoring function."""
     uniq = list({item['sequence']: item for item in simulation_data}.values())
     if oligo_state == "avoid":

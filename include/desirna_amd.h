@@ -24,6 +24,13 @@ extern "C" {
 
 typedef struct drna_engine drna_engine;
 
+/* Layout version of this interface.  Bumped whenever the meaning or size of a caller-owned buffer changes under an unchanged
+ * symbol name (2 -> 3: rng_state of drna_propose_batch[_alt] / drna_metropolis_batch / drna_mc_run became R x DRNA_RNG_WORDS
+ * uint32 MT19937 streams instead of R uint64).  A binding compares drna_abi_version() with the DRNA_ABI_VERSION it was written
+ * against at load time, so a stale caller fails there instead of overrunning a buffer. */
+#define DRNA_ABI_VERSION 3
+int drna_abi_version(void);
+
 /* return codes */
 enum {
   DRNA_OK = 0,
@@ -182,7 +189,8 @@ int drna_set_option(drna_engine *e, const char *name, int value);
 
 /* reads an option back ("dual", "strips"), or the counter "sync_fallbacks": calls in which a fold by several workgroups lost a
  * partner (a bounded wait expired -- HIP promises no dispatch order) and which were therefore redone, transparently, with one
- * workgroup per fold.  Option "strip_fault" = 1 injects such a loss into every strip launch (tests). */
+ * workgroup per fold.  Option "strip_fault" = 1 injects such a loss into every strip launch (tests).  "last_workgroups": fold
+ * workgroups (partition function + MFE kernels, resident side by side) of the last drna_score_batch call. */
 int drna_get_option(const drna_engine *e, const char *name, int *value);
 
 /* diagnostics (engine created with DRNA_STRIP_DEBUG=1 in the environment): start / end wall clocks (100 MHz ticks) of the MFE

@@ -1115,27 +1115,25 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
 #else
   (void)threads;
 #endif
-  /* bind OpenMP thread t to the t-th CPU of the process's affinity mask (taken once, before any thread is bound): without
-   * it the threads of a share-limited lease pile onto a few cores and the all-cores figure of the CPU baseline is not a
-   * statement about the cores (OMP_PROC_BIND cannot be used: set in the environment it would also bind the caller's
-   * main thread, i.e. the Python process driving the GPU) */
+  /* flags & 8 (set by bench.py's cpu_baseline leg only): bind OpenMP thread t to the t-th CPU of the caller's affinity mask
+   * for the duration of this call -- without it the threads of a share-limited lease pile onto a few cores and the all-cores
+   * figure of the CPU baseline is not a statement about the cores (OMP_PROC_BIND cannot be used: set in the environment it
+   * would also bind the caller's main thread, i.e. the Python process driving the GPU).  The masks are put back before the
+   * call returns: the worker threads belong to the process-wide libgomp pool and other OpenMP users would inherit a pin. */
 #if defined(_OPENMP) && defined(__linux__)
-  {
-    static cpu_set_t base;
-    static int have_base = 0;
-    if (!have_base) { have_base = sched_getaffinity(0, sizeof base, &base) == 0 ? 1 : -1; }
-    if (have_base == 1 && threads > 1) {
-      int ncpu = CPU_COUNT(&base);
+  cpu_set_t base;
+  const int pin = (flags & 8u) && threads > 1 && sched_getaffinity(0, sizeof base, &base) == 0;   /* thread 0 = the caller, never bound */
+  if (pin) {
+    int ncpu = CPU_COUNT(&base);
 #pragma omp parallel
-      {
-        int t = omp_get_thread_num() % (ncpu > 0 ? ncpu : 1), seen = 0;
-        for (int c = 0; c < CPU_SETSIZE; c++)
-          if (CPU_ISSET(c, &base) && seen++ == t) {
-            cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one);
-            if (omp_get_thread_num() != 0) sched_setaffinity(0, sizeof one, &one);   /* thread 0 is the caller: left alone */
-            break;
-          }
-      }
+    {
+      int t = omp_get_thread_num() % (ncpu > 0 ? ncpu : 1), seen = 0;
+      for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &base) && seen++ == t) {
+          cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one);
+          if (omp_get_thread_num() != 0) sched_setaffinity(0, sizeof one, &one);
+          break;
+        }
     }
   }
 #endif
@@ -1157,6 +1155,12 @@ void orc_score_batch(const orc_params *P, int R, int L, const char *seqs, int n_
         Ed[(size_t)r * (size_t)n_targets + (size_t)k] = orc_eval_structure(P, seq, targets + (size_t)k * (size_t)L, L);
     free(ss); free(ss2);
   }
+#if defined(_OPENMP) && defined(__linux__)
+  if (pin) {
+#pragma omp parallel
+    { if (omp_get_thread_num() != 0) sched_setaffinity(0, sizeof base, &base); }
+  }
+#endif
 }
 
 /* ---------------------------------------------------------------- two strands: co-fold MFE and partition function

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
-FLAG_PF, FLAG_MFE, FLAG_PK = 1, 2, 4
+FLAG_PF, FLAG_MFE, FLAG_PK, FLAG_PIN = 1, 2, 4, 8      # FLAG_PIN: bind worker threads to cores for this call (bench.py only)
 
 
 def build(force=False):
@@ -22,11 +22,23 @@ def build(force=False):
     return _LIB
 
 
+def build_native():
+    """bench.py's cpu_baseline leg: the same source built on THIS host with -march=native (liboracle_native.so, never shipped:
+    the dev container's CPU may differ from the GPU box's).  Returns the path, or None when the compiler refuses."""
+    out = os.path.join(_HERE, "liboracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", out,
+                               os.path.join(_HERE, "oracle.c"), "-lm"], stderr=subprocess.DEVNULL)
+        return out
+    except Exception:
+        return None
+
+
 class Oracle:
-    def __init__(self, blob):
-        if not os.path.exists(_LIB):
+    def __init__(self, blob, lib=None):
+        if lib is None and not os.path.exists(_LIB):
             build()
-        L = C.CDLL(_LIB)
+        L = C.CDLL(lib or _LIB)
         self._L = L
         L.orc_params_create.restype = C.c_void_p
         L.orc_params_create.argtypes = [C.c_void_p, C.c_int]

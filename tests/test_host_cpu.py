@@ -69,3 +69,27 @@ def test_engine_fails_loudly_without_library(tmp_path):
     from desirna_amd import engine
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE starts N ranks itself (torch.distributed.run's environment contract),
+    relays rank 0's line and fails when a rank fails; with WORLD_SIZE set (the driver's torchrun launch) it starts nothing."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DRNA_BENCH_ECHO_RANK"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1" and line["gpus"] == 3
+    ranks = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(3)]
+    assert [x["LOCAL_RANK"] for x in ranks] == ["0", "1", "2"] and len({x["MASTER_PORT"] for x in ranks}) == 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, DRNA_BENCH_ECHO_FAIL="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "ranks failed" in r.stderr
+    for f in tmp_path.iterdir():
+        f.unlink()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                       env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and sorted(x.name for x in tmp_path.iterdir()) == ["rank1.json"]      # one process: this rank only

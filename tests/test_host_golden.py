@@ -119,7 +119,7 @@ def test_proposals_same_position_and_draws():
             assert j >= 0 and set(dm) <= {pos, j} and set(dr) <= {pos, j}
             assert mine[pos] == ref[pos]                          # first letter: sorted list, deterministic
             assert mine[j] in CAN_PAIR[mine[pos]] and ref[j] in CAN_PAIR[ref[pos]]
-    assert n_exact > len(GOLD["proposals"]) // 2
+    assert n_exact == len(GOLD["proposals"])          # 900 of 900: the exemptions above never fire on the recorded vectors
     two = [c for c in GOLD["proposals"] if c.get("oligo_state", "none") != "none"]
     assert len(two) == 300          # hetero-dimer and homodimer inputs (strand-copy rules of the homodimer included)
 
