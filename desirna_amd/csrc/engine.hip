@@ -99,6 +99,10 @@ struct drna_engine {
   int flag_resets = 0;            // times the hand-over flags were zeroed because an epoch neared the compare range
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
   int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
+  bool pf_helper = true;          // small batches: a helper workgroup per sequence computes the far multiloop split points of the
+                                  // partition function (fold_pf_lds.hpp, pf_kfar_helper); option "pf_helper"
+  int* d_pflags = nullptr;        // its hand-over flags: per sequence two 128-byte lines
+  int pflags_cap = 0, pfh_epoch = 0;
   int last_wgs = 0;               // fold workgroups of the last drna_score_batch call (partition function + MFE kernels, resident side by side)
   int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
   bool in_fallback = false;
@@ -133,6 +137,7 @@ static size_t mfe_ws_stride(int ld) { return (size_t)5 * ld * ld; }             
 // hand-over flags hold (epoch << 12 | diagonal) for the strips and ((epoch * 8 + round) << 10 | diagonal) for the two-workgroup
 // kernel, compared wrap-safe: valid while live values are less than 2^31 apart, i.e. 2^19 (2^18) epochs.  Reset at a quarter of that.
 constexpr int STRIP_EPOCH_RESET = 1 << 17, DUAL_EPOCH_RESET = 1 << 16;
+constexpr int PF_HELPER_NMIN = 120;       // shorter sequences have too few far split points to repay a second workgroup
 
 // strips of a sequence of length n (0 = not a strip case): widest strip STRIP_WMAX columns; the exchange records of the
 // S - 1 strip boundaries must fit tables 0 and 1 of the sequence's workspace
@@ -296,7 +301,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   void* bufs[] = {e->d_mfeT, e->d_pfT, e->d_plan, e->d_hp_len, e->d_bulge_len, e->d_int_len, e->d_hp_w, e->d_scale,
                   e->d_eMLb, e->d_ws_mfe, e->d_ws_pf, e->d_seqs, e->d_Epf, e->d_Emfe, e->d_ss, e->d_Ed, e->d_pt,
                   e->d_ws_out, e->d_edef, e->d_rg, e->d_rpt, e->d_rpt_off, e->d_F4, e->d_ws_kb, e->d_kbE, e->d_kbss,
-                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg, e->d_sclk};
+                  e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe, e->d_sflags, e->d_srec, e->d_sdbg, e->d_sclk, e->d_pflags};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
@@ -320,9 +325,10 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
+  if (!strcmp(name, "pf_helper")) { e->pf_helper = value != 0; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
-  if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
+  if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; e->pfh_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
   e->err = std::string("drna_set_option: unknown option ") + name;
   return DRNA_ERR_ARG;
 }
@@ -340,10 +346,11 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!e || !name || !value) return DRNA_ERR_ARG;
   if (!strcmp(name, "dual")) { *value = e->dual ? (e->dual_force ? 2 : 1) : 0; return DRNA_OK; }
   if (!strcmp(name, "strips")) { *value = e->strips; return DRNA_OK; }
+  if (!strcmp(name, "pf_helper")) { *value = e->pf_helper ? 1 : 0; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
   if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
   if (!strcmp(name, "flag_resets")) { *value = e->flag_resets; return DRNA_OK; }
-  if (!strcmp(name, "debug_epoch")) { *value = e->strip_epoch > e->dual_epoch ? e->strip_epoch : e->dual_epoch; return DRNA_OK; }
+  if (!strcmp(name, "debug_epoch")) { *value = std::max(e->pfh_epoch, std::max(e->strip_epoch, e->dual_epoch)); return DRNA_OK; }
   return DRNA_ERR_ARG;
 }
 
@@ -445,6 +452,28 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   const int pf_strips = want_pf ? strips_for(e, L, ld) : 0;
   const int mfe_strips = want_mfe ? strips_for(e, L, ld) : 0;
   e->last_wgs = 0;
+  // partition function of a small batch: a helper workgroup per sequence on a CU that would idle takes the far multiloop split
+  // points (the main workgroup's vector-memory path is what they saturate); needs room for 2 R workgroups beside the MFE fold's
+  const int mfe_wgs = want_mfe ? (use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R) : 0;
+  const bool pf_help = want_pf && e->pf_helper && !pf_strips && e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX && L >= PF_HELPER_NMIN &&
+                       2 * R + mfe_wgs <= e->cus;
+  if (pf_help) {
+    if (e->pflags_cap < R) {
+      if (e->d_pflags) (void)hipFree(e->d_pflags);
+      e->d_pflags = nullptr; e->pflags_cap = 0;
+      HIP_TRY(hipMalloc((void**)&e->d_pflags, (size_t)R * 64 * sizeof(int)));
+      HIP_TRY(hipMemset(e->d_pflags, 0, (size_t)R * 64 * sizeof(int)));
+      HIP_TRY(hipDeviceSynchronize());
+      e->pflags_cap = R; e->pfh_epoch = 0;
+    }
+    if (e->pfh_epoch >= STRIP_EPOCH_RESET) {                       // see strip_flags(): 4096 flag values per epoch
+      HIP_TRY(hipMemset(e->d_pflags, 0, (size_t)e->pflags_cap * 64 * sizeof(int)));
+      HIP_TRY(hipDeviceSynchronize());
+      e->pfh_epoch = 0;
+      e->flag_resets++;
+    }
+    e->pfh_epoch++;
+  }
   if (pf_strips || mfe_strips) { const int rc = strip_flags(e, mfe_strips != 0); if (rc != DRNA_OK) return rc; }
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
@@ -456,9 +485,12 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    e->last_wgs += pf_strips ? R * pf_strips : R;
+    e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
-    else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
+    else if (pf_help) {
+      a.helper = 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12);
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a);
+    } else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
@@ -562,10 +594,10 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       // HIP promises no dispatch order: a multi-workgroup fold whose bounded wait expired is not an error of the batch -- the
       // whole call is redone with one workgroup per fold (general / LDS-resident kernels), which need nobody
       const int s_strips = e->strips;
-      const bool s_dual = e->dual;
-      e->in_fallback = true; e->strips = 0; e->dual = false;
+      const bool s_dual = e->dual, s_help = e->pf_helper;
+      e->in_fallback = true; e->strips = 0; e->dual = false; e->pf_helper = false;
       const int rc = drna_score_batch_device(e, R, L, d_seqs, flags, d_Epf, d_Emfe, d_mfe_ss, d_Ed);
-      e->strips = s_strips; e->dual = s_dual; e->in_fallback = false;
+      e->strips = s_strips; e->dual = s_dual; e->pf_helper = s_help; e->in_fallback = false;
       e->sync_fallbacks++;
       return rc;
     }

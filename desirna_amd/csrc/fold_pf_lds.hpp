@@ -45,7 +45,8 @@ struct PfFastSmem {
   double hpw[PF_FAST_NMAX + 2];   // hairpin weight by loop size (scale folded in)
   double q5[PF_FAST_NMAX + 2];
   double partG[2][2][NSLOT];      // tower sums, one slice per parity of the loop size
-  double partK[2][4][NSLOT];      // multiloop sums, one slice per split-point group
+  double partK[2][4][NSLOT];      // multiloop sums, near split points: one slice per row
+  double partF[2][4][NSLOT];      // far split points (when no helper workgroup computes them): one slice per sub-sum
   double accE[2][NSLOT], accX[2][3][NSLOT];   // accX: one slice per group of fixed shapes
   // Boltzmann tables
   double stack[64], mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128], int11[1024], d5[32], d3[32];
@@ -194,6 +195,80 @@ __device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL],
   return (acc0 + acc1) + acc2;
 }
 
+
+// ---- multiloop sums D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j], tt = TURN+1 .. d-TURN-2, in ONE canonical order (round 3).
+// The split points of a cell are cut into a NEAR part -- the KLAG - 5 first and the KLAG - 5 last, whose longer operand is
+// younger than KLAG diagonals -- and a FAR part (both operands at least KLAG diagonals old, tt = KLAG-1 .. d-KLAG, from
+// diagonal KDF0 on).  The far part needs nothing recent, so in small batches a HELPER workgroup on an idle CU computes it
+// from rows the main workgroup publishes (pf_kfar_helper) and the main workgroup, whose vector-memory path the multiloop
+// operands saturate (21 MB per fold through 64 B/clk: 0.15 of 0.58 ms), keeps 14 split points per cell.  Without a helper
+// the main workgroup works the far part itself, through the same functions and in the same order, so Epf does not depend on
+// which way a batch was run: per cell, near = (r0 + r1) + (r2 + r3) over four interleaved rows of at most four split points
+// (fma chains over x = row, row + 8 and x = row + 4, row + 12, added), far = sum over the kfar_subs(ncell) sub-sums in
+// order, each the fold (r0 + r1) + (r2 + r3) of four rows that walk their interleaved split points with two alternating
+// fma chains; D = near + far.
+constexpr int KLAG = 12;
+constexpr int KDF0 = 2 * KLAG - 1;      // first diagonal with a far split point
+constexpr int KNL = KLAG - 1 - (TURN + 1);   // near split points at either end
+constexpr int KROUND = 4;               // diagonals per round of the helper
+__host__ __device__ inline int kfar_sub_shift(int ncell) { return ncell > 96 ? 0 : ncell > 32 ? 1 : 2; }
+
+template <bool SC1, typename RS>
+__device__ __forceinline__ f64x2 k_load2(RS rs, int voff, int soff) {
+  if (SC1) return buf_load_f64x2_sc1(rs, voff, soff);
+  return buf_load_f64x2(rs, voff, soff);
+}
+
+// far sub-sum: row `g` of KGf interleaved rows, cells i and i+1 of diagonal d (operands: table at byte 0 = qm, at tab8 = qm1)
+template <bool SC1, typename RS>
+__device__ __forceinline__ void k_far_row(RS rs, int tab8, int ld, int d, int i, int g, int KGf, double& v0, double& v1) {
+  double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
+  int tt = KLAG - 1 + g;
+  const int tmax = d - KLAG;
+  const int astep = 8 * KGf * ld, cstep = 8 * KGf * (ld - 1);
+  // byte offsets: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at tab8 + ((d-tt-1) ld + i+tt+1) 8; a step of KGf in tt moves them
+  // by +8 KGf ld and -(8 KGf ld - 8 KGf)
+  int vA = (tt * ld + i) * 8;
+  int vC = tab8 + ((d - tt - 1) * ld + i + tt + 1) * 8;
+  for (; tt + 3 * KGf <= tmax; tt += 4 * KGf) {
+    const int vCl = vC - 3 * cstep;                                       // operand of tt + 3 KGf: in range here
+    const f64x2 a0 = k_load2<SC1>(rs, vA, 0), c0 = k_load2<SC1>(rs, vCl, 3 * cstep);
+    const f64x2 a1 = k_load2<SC1>(rs, vA, astep), c1 = k_load2<SC1>(rs, vCl, 2 * cstep);
+    const f64x2 a2 = k_load2<SC1>(rs, vA, 2 * astep), c2 = k_load2<SC1>(rs, vCl, cstep);
+    const f64x2 a3 = k_load2<SC1>(rs, vA, 3 * astep), c3 = k_load2<SC1>(rs, vCl, 0);
+    vA += 4 * astep; vC -= 4 * cstep;
+    p0 = fma(a0.x, c0.x, p0); q0 = fma(a0.y, c0.y, q0); p1 = fma(a1.x, c1.x, p1); q1 = fma(a1.y, c1.y, q1);
+    p0 = fma(a2.x, c2.x, p0); q0 = fma(a2.y, c2.y, q0); p1 = fma(a3.x, c3.x, p1); q1 = fma(a3.y, c3.y, q1);
+  }
+  for (; tt <= tmax; tt += KGf) {
+    const f64x2 a0 = k_load2<SC1>(rs, vA, 0), c0 = k_load2<SC1>(rs, vC, 0);
+    p0 = fma(a0.x, c0.x, p0); q0 = fma(a0.y, c0.y, q0);
+    vA += astep; vC -= cstep;
+  }
+  v0 = p0 + p1; v1 = q0 + q1;
+}
+
+// near part: row `row` of four takes the split points x = row, row + 4, row + 8, row + 12 of the near list
+// (x < KNL: tt = TURN+1 + x; else tt = TURN+1 + x + F, F = number of far split points in between)
+template <typename RS>
+__device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i, int row, int F, double& v0, double& v1) {
+  const int Nn = d - 2 * (TURN + 1) - F;
+  f64x2 a[4], c[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int x = row + 4 * u;
+    const bool ok = x < Nn;
+    const int xx = ok ? x : 0;
+    const int tt = TURN + 1 + xx + (xx >= KNL ? F : 0);
+    a[u] = buf_load_f64x2(rs, (tt * ld + i) * 8, 0);
+    c[u] = buf_load_f64x2(rs, tab8 + ((d - tt - 1) * ld + i + tt + 1) * 8, 0);
+    if (!ok) { a[u].x = 0.0; a[u].y = 0.0; c[u].x = 0.0; c[u].y = 0.0; }
+  }
+  const double p0 = fma(a[2].x, c[2].x, fma(a[0].x, c[0].x, 0.0)), p1 = fma(a[3].x, c[3].x, fma(a[1].x, c[1].x, 0.0));
+  const double q0 = fma(a[2].y, c[2].y, fma(a[0].y, c[0].y, 0.0)), q1 = fma(a[3].y, c[3].y, fma(a[1].y, c[1].y, 0.0));
+  v0 = p0 + p1; v1 = q0 + q1;
+}
+
 // Diagnostic builds only (-DDRNA_SKIP=mask, tools/phase_cost.py): leave out a sweep phase to read its marginal cost
 // from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = cell finalize, 32 = table / pairable-list
 // preparation, 64 = exterior column.
@@ -208,15 +283,85 @@ __device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL],
 #endif
 #endif
 
+// ---- helper workgroup of pf_lds_kernel (small batches: idle CUs): the FAR multiloop split points of every cell, from the
+// rows the main workgroup publishes.  Hand-over as the CDNA4 guide prescribes (and as fold_mfe_dual.hpp does it): payload by
+// sc1 stores into tables of its own (XQM, XQM1: tables 0 and 1 of the sequence's workspace, which this kernel does not use
+// otherwise -- the main workgroup's own reads stay on plain-stored QM / QM1, whose lines remain in its L2), every storing wave
+// drained, workgroup barrier, ONE lane stores the flag; the consumer polls the flag from one wave and loads the payload
+// only afterwards, sc1.  One-way slack instead of a per-step round trip: diagonal d needs rows <= d - KLAG only and is due
+// KLAG steps after the last of them, so the helper works KROUND diagonals per round (enough items for sixteen waves, one set
+// of barriers) and stays ahead of the main workgroup's need by itself.  Results travel back through DFAR (table 5).
 template <int NT>
-__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
-  __shared__ PfFastSmem<NT> sm;              // the kernel's only LDS object: offset 0
+__device__ void pf_kfar_helper(const PfArgs& A, PfFastSmem<NT>& sm, int r, int n) {
+  constexpr int NW = NT / WAVE;
+  const int ld = A.ld, tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  double* base = A.ws + (long long)r * A.ws_stride;
+  const long long tab = (long long)ld * ld;
+  double* DFAR = base + 5 * tab;
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)(2 * tab * 8), 0x00020000);     // XQM, XQM1
+  const int* flagA = A.hflags + (long long)r * 64;
+  int* flagB = A.hflags + (long long)r * 64 + 32;
+  double* part = reinterpret_cast<double*>(&sm);              // [KROUND][4][256] sub-sums by cell (the ring is not used here)
+  int* ctl = reinterpret_cast<int*>(part + KROUND * 4 * 256);
+  for (int k = tid; k < KROUND * 4 * 256; k += NT) part[k] = 0.0;
+  if (tid == 0) ctl[0] = 0;
+  __syncthreads();
+  for (int d0 = KDF0; d0 < n; d0 += KROUND) {
+    const int dmax = min(d0 + KROUND - 1, n - 1);
+    if (wave == 0) {
+      int seen = 0;
+      const bool ok = strip_wait(flagA, A.hbase, dmax - KLAG, seen);
+      if (lane == 0 && (!ok || seen == A.hbase + STRIP_DONE)) ctl[0] = 1;        // the main workgroup is gone (bad character) or lost
+    }
+    __syncthreads();
+    if (ctl[0]) break;
+    // items (diagonal, 32-cell block, sub-sum), dealt to the waves in order
+    int itbase = 0;
+    for (int dd = 0; dd <= dmax - d0; dd++) {
+      const int d = d0 + dd, ncell = n - d, kfsh = kfar_sub_shift(ncell);
+      const int cnt = ((ncell + 31) >> 5) << kfsh;
+      for (int it = (wave + NW - itbase % NW) % NW; it < cnt; it += NW) {
+        const int blk = it >> kfsh, sub = it & ((1 << kfsh) - 1), cl = lane & 15, row = lane >> 4;
+        int i = (blk << 5) + 2 * cl + 1;
+        const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
+        i = act0 ? i : 1;
+        double v0, v1;
+        k_far_row<true>(rsX, (int)tab * 8, ld, d, i, sub * 4 + row, 4 << kfsh, v0, v1);
+        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+        if (lane < 16) {
+          if (act0) part[(dd * 4 + sub) * 256 + i] = v0;
+          if (act1) part[(dd * 4 + sub) * 256 + i + 1] = v1;
+        }
+      }
+      itbase += cnt;
+    }
+    __syncthreads();
+    for (int t = tid; t < KROUND * 256; t += NT) {
+      const int dd = t >> 8, i = t & 255, d = d0 + dd;
+      if (d <= dmax && i >= 1 && i <= n - d) {
+        const double* p = part + dd * 4 * 256 + i;
+        st_agent(&DFAR[d * ld + i], ((p[0] + p[256]) + p[512]) + p[768]);       // the order pf_lds_kernel's finalize uses for partF
+      }
+    }
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0) st_agent(flagB, A.hbase + dmax);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
-  const int r = A.rg.idx ? A.rg.idx[blockIdx.x] : blockIdx.x;
+  const bool hm = A.helper != 0;                     // a helper workgroup (odd blocks) computes the far multiloop split points
+  const int bx = hm ? blockIdx.x >> 1 : blockIdx.x;
+  const int r = A.rg.idx ? A.rg.idx[bx] : bx;
   if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
+  if (hm && (blockIdx.x & 1)) { pf_kfar_helper<NT>(A, sm, r, n); return; }
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
 
@@ -277,7 +422,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   for (int k = tid; k < 32 * RS; k += NT) { sm.qbi[k] = 0.0; sm.info[k] = 0; }
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
-  for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
+  for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) { (&sm.partK[0][0][0])[k] = 0.0; (&sm.partF[0][0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accE[0][0])[k] = 0.0;
   for (int k = tid; k < 6 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accX[0][0][0])[k] = 0.0;
   if (tid == 0) { sm.flag = 0; sm.q5[0] = 1.0; }
@@ -292,7 +437,7 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   if (tid == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
   __syncthreads();
   if (sm.flag) {
-    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Epf[r] = 0.0; }
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Epf[r] = 0.0; if (hm) st_agent(A.hflags + (long long)r * 64, A.hbase + STRIP_DONE); }
     return;
   }
   if (wave == 0) {                                   // q5[j] = scale^j while no pair fits (j <= TURN + 1)
@@ -357,6 +502,11 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
 
 
+  double* XQM = base, *XQM1 = base + tab, *DFAR = base + 5 * tab;      // exchange tables of the helper hand-over (tables 0, 1, 5)
+  int* flagA = hm ? A.hflags + (long long)r * 64 : nullptr;
+  const int* flagB = hm ? A.hflags + (long long)r * 64 + 32 : nullptr;
+  double dfar_cur = 0.0, dfar_next = 0.0;
+  bool dfar_pending = false;
   // Floating work items of diagonal d, taken from a work queue (LDS counter).  The sweep waves run this after their tower
   // step; the finalize waves, which are done with diagonal d-1 long before the sweep of d ends, join in: every item owns
   // its output slots and reads nothing the current step writes, so the result does not depend on who takes it.
@@ -368,65 +518,37 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
     // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
     // not depend on which wave takes it.
-    // K items per 32-cell block: 4 once a single block is left
-    const int kssh = ncell <= 32 ? 2 : 0, KS = 1 << kssh, KG = 4 << kssh;
-    const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
-    const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2,
-              nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
+    // K items: per 32-cell block one NEAR item and, where no helper workgroup does that part, kfar_subs FAR items (see k_far_row)
+    const int nblk = (ncell + 31) >> 5;
+    const int F = d >= KDF0 ? d - 2 * KLAG + 2 : 0;            // far split points of this diagonal's cells
+    const int kfsh = kfar_sub_shift(ncell);
+    const int nKf = ((DRNA_SKIP & 8) || hm || F == 0) ? 0 : nblk << kfsh;
+    const int nK = nKf + (((DRNA_SKIP & 8) || d < 2 * TURN + 3) ? 0 : nblk);
+    const int nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2, nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
     for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
       if (it < nK) {
-        // ---- K: multiloop sum D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j] for 32 cells x 4 interleaved split-point
-        // groups: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
+        // ---- K: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
         // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
-        // When few blocks are left (late diagonals: few cells, long sums) a block's split points are dealt to KS = 2 or 4
-        // items, so that no wave walks the whole sum as one chain of dependent L2 round trips while the others idle;
-        // the rows of such an item are folded inside the wave so that the four slices still suffice.
-        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
-        int i = ((it >> kssh) << 5) + 2 * cl + 1;
+        const bool far = it < nKf;
+        const int blk = far ? it >> kfsh : it - nKf, cl = lane & 15, row = lane >> 4;
+        int i = (blk << 5) + 2 * cl + 1;
         const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
         i = act0 ? i : 1;
-        double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
-        int tt = TURN + 1 + g;
-        // byte offsets from QM: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at (tab + (d-tt-1) ld + i+tt+1) 8;
-        // a step of KG = 4 KS in tt moves them by +8 KG ld and -(8 KG ld - 8 KG) bytes
-        int vA = (tt * ld + i) * 8;
-        int vC = (int)tab * 8 + ((d - tt - 1) * ld + i + tt + 1) * 8;          // operand of tt (never negative)
-#ifdef DRNA_KFAKE
-        const int tmax = min(d - TURN - 2, TURN + DRNA_KFAKE);                  // timing experiments only: the first DRNA_KFAKE terms
-#else
-        const int tmax = d - TURN - 2;
-#endif
-        for (; tt + 3 * KG <= tmax; tt += 4 * KG) {
-          const int vCl = vC - 3 * cstep;                                       // operand of tt + 3 KG: in range here
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vCl, 3 * cstep);
-          const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1 = buf_load_f64x2(rsQ, vCl, 2 * cstep);
-          const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2 = buf_load_f64x2(rsQ, vCl, cstep);
-          const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3 = buf_load_f64x2(rsQ, vCl, 0);
-          vA += 4 * astep; vC -= 4 * cstep;
-          p0 += a0.x * c0.x; q0 += a0.y * c0.y; p1 += a1.x * c1.x; q1 += a1.y * c1.y;
-          p0 += a2.x * c2.x; q0 += a2.y * c2.y; p1 += a3.x * c3.x; q1 += a3.y * c3.y;
-        }
-        for (; tt <= tmax; tt += KG) {
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0 = buf_load_f64x2(rsQ, vC, 0);
-          p0 += a0.x * c0.x; q0 += a0.y * c0.y;
-          vA += astep; vC -= cstep;
-        }
-        double v0 = p0 + p1, v1 = q0 + q1;
-        int slice = lane >> 4;
-        bool writer = true;
-        if (kssh >= 1) {                       // rows 0+1 and 2+3
+        double v0, v1;
+        if (far) {
+          const int sub = it & ((1 << kfsh) - 1);
+          k_far_row<false>(rsQ, (int)tab * 8, ld, d, i, sub * 4 + row, 4 << kfsh, v0, v1);
           v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-          slice = (it & (KS - 1)) * (4 >> kssh) + (lane >> 5);
-          writer = (lane & 16) == 0;
-        }
-        if (kssh == 2) {                       // all four rows
           v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-          writer = lane < 16;
-        }
-        if (writer) {
-          if (act0) sm.partK[par][slice][i + slot0] = v0;
-          if (act1) sm.partK[par][slice][i + 1 + slot0] = v1;
+          if (lane < 16) {
+            if (act0) sm.partF[par][sub][i + slot0] = v0;
+            if (act1) sm.partF[par][sub][i + 1 + slot0] = v1;
+          }
+        } else {
+          k_near_row(rsQ, (int)tab * 8, ld, d, i, row, F, v0, v1);
+          if (act0) sm.partK[par][row][i + slot0] = v0;
+          if (act1) sm.partK[par][row][i + 1 + slot0] = v1;
         }
       } else if (it < nK + nE) {
         // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots (two staged halves:
@@ -514,15 +636,32 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
     // ================= finalize waves: diagonal d = k-1 at step k
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
+      int fbv = 0;
+      if (hm) {
+        // diagonal k-2 was finalized in step k-1 and every store of it drained by that step's barrier: publish it
+        if (tid == 0 && k - 2 > TURN) st_agent(flagA, A.hbase + (k - 2));
+        if (dfar_pending) {                        // the far sums of diagonal d were not there yet a step ago: wait for them now
+          int seen = 0;
+          if (!strip_wait(flagB, A.hbase, d, seen)) sm.flag = 2;
+          const int ic = tid + 1 - (d >> 1) - off0;
+          dfar_next = (ic >= 1 && ic <= n - d) ? ld_agent(&DFAR[d * ld + ic]) : 0.0;
+          dfar_pending = false;
+        }
+        dfar_cur = dfar_next;
+        fbv = ld_agent(flagB);                     // requested here, looked at after the cell finalize
+      }
       if (d > TURN) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
         if (!(DRNA_SKIP & 16) && i >= 1 && i <= ncell) {
           const double aG = sm.partG[par][0][tid] + sm.partG[par][1][tid];
-          const double aK = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
+          const double aKn = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
+          const double aKf = hm ? dfar_cur : ((sm.partF[par][0][tid] + sm.partF[par][1][tid]) + sm.partF[par][2][tid]) + sm.partF[par][3][tid];
+          const double aK = aKn + aKf;
           const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
           sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0;
           sm.partK[par][0][tid] = 0.0; sm.partK[par][1][tid] = 0.0; sm.partK[par][2][tid] = 0.0; sm.partK[par][3][tid] = 0.0;
+          sm.partF[par][0][tid] = 0.0; sm.partF[par][1][tid] = 0.0; sm.partF[par][2][tid] = 0.0; sm.partF[par][3][tid] = 0.0;
           sm.accE[par][tid] = 0.0; sm.accX[par][0][tid] = 0.0; sm.accX[par][1][tid] = 0.0; sm.accX[par][2][tid] = 0.0;
           const int j = i + d;
           const int t = pair_type(sm.S[i], sm.S[j]);
@@ -572,7 +711,15 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
           sm.dring[(d & 3) * RS + i] = aK;
           QM1[d * ld + i] = m1;
           QM[d * ld + i] = m1 + aK + U;
+          if (hm) { st_agent(&XQM1[d * ld + i], m1); st_agent(&XQM[d * ld + i], m1 + aK + U); }
         }
+      }
+      if (hm && k >= KDF0 && k < n) {
+        // far sums of the next diagonal (k), one step ahead: loaded only once the helper's flag shows them published
+        if (flag_ge(__builtin_amdgcn_readfirstlane(fbv), A.hbase + k)) {
+          const int ic = tid + 1 - (k >> 1) - off0;
+          dfar_next = (ic >= 1 && ic <= n - k) ? ld_agent(&DFAR[k * ld + ic]) : 0.0;
+        } else dfar_pending = true;
       }
       // side jobs of the step, one finalize wave each (when there are that many): tower table of diagonal k+1,
       // pairable list of diagonal k+1, exterior column j = k-3 (its cells were stored in step <= k-3 and drained by
@@ -660,11 +807,18 @@ __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
         A.status[r] = ST_PF_RANGE;
         A.Epf[r] = 0.0;
       } else {
-        A.status[r] = ST_OK;
+        A.status[r] = sm.flag == 2 ? ST_SYNC : ST_OK;             // 2: a wait for the helper workgroup expired (the engine redoes the call without one)
         A.Epf[r] = (-log(Z) - (double)n * log(T.pf_scale)) * T.kT / 1000.0;
       }
+      if (hm) st_agent(flagA, A.hbase + STRIP_DONE);
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
+  __shared__ PfFastSmem<NT> sm;
+  pf_lds_body<NT>(sm, A);
 }
 
 }  // namespace drna

@@ -195,14 +195,26 @@ int emu_pf(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int
     a.eMLb = c->H.eMLb.data(); a.seqs = seqs; a.L = L; a.ld = ld;
     a.ws = ws.data() - (size_t)r * stride; a.ws_stride = (long long)stride;
     a.Epf = Epf; a.status = status;
+    // nt = -257 / -1025: the LDS-resident kernel with a helper workgroup per sequence (far multiloop split points), side by side
+    const bool helper = nt == -257 || nt == -1025;
+    std::vector<int> hflags(64, 0);
+    if (helper) { a.helper = 1; a.hflags = hflags.data() - (size_t)r * 64; a.hbase = 3 << 12; }
     auto fn = [&]() {
       if (nt == 64) pf_kernel<64>(a);
       else if (nt == 128) pf_kernel<128>(a);
       else if (nt == 256) pf_kernel<256>(a);
-      else if (nt == -256) pf_lds_kernel<256>(a);
+      else if (nt == -256 || nt == -257) pf_lds_kernel<256>(a);
       else pf_lds_kernel<1024>(a);
     };
-    emu_launch(r, nt < 0 ? -nt : nt, fn);
+    if (helper) {           // two workgroups side by side, each with an LDS image of its own
+      auto* s256 = new PfFastSmem<256>[2];
+      auto* s1024 = new PfFastSmem<1024>[2];
+      std::vector<std::function<void()>> fns;
+      for (int b = 0; b < 2; b++)
+        fns.push_back([&, b]() { if (nt == -257) pf_lds_body<256>(s256[b], a); else pf_lds_body<1024>(s1024[b], a); });
+      emu_launch_many(2 * r, nt == -257 ? 256 : 1024, fns);
+      delete[] s256; delete[] s1024;
+    } else emu_launch(r, nt < 0 ? -nt : nt, fn);
   }
   delete c;
   return 0;
