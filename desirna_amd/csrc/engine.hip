@@ -1454,7 +1454,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
   return DRNA_OK;
 }
 
-#if defined(DRNA_STAMPS) || defined(DRNA_STAMPS_API)
+#if defined(DRNA_STAMPS) || defined(DRNA_STAMPS_API) || defined(DRNA_TL)
 // diagnostic build only: copy `count` int32 of the MFE workspace starting at int32 offset `off`
 extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, int32_t* out) {
   if (!e || !out) return DRNA_ERR_ARG;

@@ -207,10 +207,16 @@ __device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL],
 // (fma chains over x = row, row + 8 and x = row + 4, row + 12, added), far = sum over the kfar_subs(ncell) sub-sums in
 // order, each the fold (r0 + r1) + (r2 + r3) of four rows that walk their interleaved split points with two alternating
 // fma chains; D = near + far.
-constexpr int KLAG = 12;
+#ifndef DRNA_KLAG
+#define DRNA_KLAG 12
+#endif
+#ifndef DRNA_KROUND
+#define DRNA_KROUND 4
+#endif
+constexpr int KLAG = DRNA_KLAG;
 constexpr int KDF0 = 2 * KLAG - 1;      // first diagonal with a far split point
 constexpr int KNL = KLAG - 1 - (TURN + 1);   // near split points at either end
-constexpr int KROUND = 4;               // diagonals per round of the helper
+constexpr int KROUND = DRNA_KROUND;     // diagonals per round of the helper
 __host__ __device__ inline int kfar_sub_shift(int ncell) { return ncell > 96 ? 0 : ncell > 32 ? 1 : 2; }
 
 template <bool SC1, typename RS>
@@ -274,6 +280,15 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 // preparation, 64 = exterior column.
 #ifndef DRNA_SKIP
 #define DRNA_SKIP 0
+#endif
+// -DDRNA_TL (tools/timeline.py): every wave of sequence 0's main workgroup stores a raw clock at three points of every step
+// (0 after the barrier, 1 after the finalize / tower step, 2 after its last item) into the unused upper half of table 4
+#ifdef DRNA_TL
+#define TLMARK(ev, k) do { if (tl_on && lane == 0) tl[((wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
+#define TLMARK2(ev, k) do { if (tl_on && lane == 0) tl[((48 + wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define TLMARK(ev, k) do { } while (0)
+#define TLMARK2(ev, k) do { } while (0)
 #endif
 #ifndef STAMP
 #ifdef DRNA_STAMPS
@@ -491,6 +506,10 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
   }
   __syncthreads();
 
+#ifdef DRNA_TL
+  long long* tl = reinterpret_cast<long long*>(base + 4 * tab + tab / 2);
+  const bool tl_on = r == 0;
+#endif
 #ifdef DRNA_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
@@ -506,7 +525,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
   int* flagA = hm ? A.hflags + (long long)r * 64 : nullptr;
   const int* flagB = hm ? A.hflags + (long long)r * 64 + 32 : nullptr;
   double dfar_cur = 0.0, dfar_next = 0.0;
-  bool dfar_pending = false;
+  int fb_last = 0;                  // (a zero flag never compares as published: epochs start at 1)
   // Floating work items of diagonal d, taken from a work queue (LDS counter).  The sweep waves run this after their tower
   // step; the finalize waves, which are done with diagonal d-1 long before the sweep of d ends, join in: every item owns
   // its output slots and reads nothing the current step writes, so the result does not depend on who takes it.
@@ -636,41 +655,81 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
     // ================= finalize waves: diagonal d = k-1 at step k
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
-      int fbv = 0;
+      TLMARK(0, k);
+      // side jobs of the step, one finalize wave each (when there are that many): pairable list of diagonal k+1, exterior
+      // column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier).  Their global loads are
+      // REQUESTED here, before this step's stores, and consumed after the cell finalize: vector-memory operations retire in
+      // order, so a wait for them does not wait for the (write-through) stores behind them.
+      const bool job_pl = !(DRNA_SKIP & 32) && k + 1 < n && wave == w_pl;
+      const bool job_q5 = !(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2;
+      int pl_cnt = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
+      if (job_pl) {
+        const int32_t* row = PL + (k + 1) * ld;
+        pl_cnt = row[ld - 1];
+        pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
+      }
+      double qx0 = 0.0, qx1 = 0.0, qx2 = 0.0, qx3 = 0.0;
+      if (job_q5) {
+        const int j = k - 3, top = j - TURN - 1;                   // i = 1 .. top
+        const double* col = QEXT + j * ld;
+        qx0 = lane + 1 <= top ? col[lane + 1] : 0.0;
+        qx1 = lane + 1 + WAVE <= top ? col[lane + 1 + WAVE] : 0.0;
+        qx2 = lane + 1 + 2 * WAVE <= top ? col[lane + 1 + 2 * WAVE] : 0.0;
+        qx3 = lane + 1 + 3 * WAVE <= top ? col[lane + 1 + 3 * WAVE] : 0.0;
+      }
+      int f_req = 0;
+      double d_req = 0.0;
       if (hm) {
         // diagonal k-2 was finalized in step k-1 and every store of it drained by that step's barrier: publish it
         if (tid == 0 && k - 2 > TURN) st_agent(flagA, A.hbase + (k - 2));
-        if (dfar_pending) {                        // the far sums of diagonal d were not there yet a step ago: wait for them now
-          int seen = 0;
-          if (!strip_wait(flagB, A.hbase, d, seen)) sm.flag = 2;
-          const int ic = tid + 1 - (d >> 1) - off0;
-          dfar_next = (ic >= 1 && ic <= n - d) ? ld_agent(&DFAR[d * ld + ic]) : 0.0;
-          dfar_pending = false;
-        }
         dfar_cur = dfar_next;
-        fbv = ld_agent(flagB);                     // requested here, looked at after the cell finalize
+        // The helper's flag and the far sums of the next diagonal are REQUESTED here and taken over at the end of the step
+        // (after the items): assigning the loop-carried variables here would make the compiler wait for the loads at once.
+        f_req = ld_agent(flagB);
+        if (k >= KDF0 && k < n) {
+          // the flag value of the previous step decides (the helper runs rounds ahead, an old value will do)
+          if (!flag_ge(fb_last, A.hbase + k)) {       // rare: the helper is not a step ahead -- wait here
+            int seen = 0;
+            if (!strip_wait(flagB, A.hbase, k, seen)) sm.flag = 2;
+          }
+          const int ic = tid + 1 - (k >> 1) - off0;
+          d_req = (ic >= 1 && ic <= n - k) ? ld_agent(&DFAR[k * ld + ic]) : 0.0;
+        }
       }
+      TLMARK2(0, k);
       if (d > TURN) {
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int i = tid + 1 - sh - off0;
         if (!(DRNA_SKIP & 16) && i >= 1 && i <= ncell) {
-          const double aG = sm.partG[par][0][tid] + sm.partG[par][1][tid];
-          const double aKn = (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]);
-          const double aKf = hm ? dfar_cur : ((sm.partF[par][0][tid] + sm.partF[par][1][tid]) + sm.partF[par][2][tid]) + sm.partF[par][3][tid];
-          const double aK = aKn + aKf;
-          const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
-          sm.partG[par][0][tid] = 0.0; sm.partG[par][1][tid] = 0.0;
-          sm.partK[par][0][tid] = 0.0; sm.partK[par][1][tid] = 0.0; sm.partK[par][2][tid] = 0.0; sm.partK[par][3][tid] = 0.0;
-          sm.partF[par][0][tid] = 0.0; sm.partF[par][1][tid] = 0.0; sm.partF[par][2][tid] = 0.0; sm.partF[par][3][tid] = 0.0;
-          sm.accE[par][tid] = 0.0; sm.accX[par][0][tid] = 0.0; sm.accX[par][1][tid] = 0.0; sm.accX[par][2][tid] = 0.0;
+          // every producer writes its slot of every live cell on every diagonal it exists for, so nothing is zeroed here:
+          // a family that does not exist yet (or a cell that cannot pair) is simply not read
           const int j = i + d;
-          const int t = pair_type(sm.S[i], sm.S[j]);
+          const int si = sm.S[i], sj = sm.S[j], si1 = sm.S[i + 1], sj1 = sm.S[j - 1], sim = sm.S[i - 1], sjp = sm.S[j + 1];
+          const double aG = d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
+          const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
+          double aKf = 0.0;
+          if (hm) aKf = dfar_cur;
+          else if (d >= KDF0) {                    // ((p0 + p1) + p2) + p3 with the sub-sums that exist (the others count as zero)
+            const int kfsh = kfar_sub_shift(ncell);
+            aKf = sm.partF[par][0][tid];
+            if (kfsh >= 1) aKf += sm.partF[par][1][tid];
+            if (kfsh >= 2) aKf = (aKf + sm.partF[par][2][tid]) + sm.partF[par][3][tid];
+          }
+          const double aK = aKn + aKf;
+          const int t = pair_type(si, sj);
           const double tau = t > 2 ? eTau : 1.0;
+          const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
+          const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
+          const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
+          const double wH = sm.mmH[ij], wI = sm.mmI[ij], wMc = sm.mmM[rt * 16 + sj1 * 4 + si1], wInfo = sm.mmI[info];
+          const double dprev = sm.dring[((d - 2) & 3) * RS + i + 1];
+          const int ex = t * 16 + sim * 4 + sjp;
+          const double wExt = sm.mmExt[ex], wMs = sm.mmM[ex], w5 = sm.d5[t * 4 + sim], w3 = sm.d3[t * 4 + sjp];
+          const int pp = (d - 1) & 1;
+          const double m1p = sm.qm1row[pp][i], m1q = sm.qm1row[pp][i + 1], up = sm.urow[pp][i + 1];
           double qb = 0.0;
-          int info = 0;
           if (t) {
             const int u = d - 1;
-            const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
             double hp;
             if (u == 3 || u == 4 || u == 6) {
               // special hairpins (tri / tetra / hexa loops) go through the general routine
@@ -681,63 +740,52 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
               if (u == 3) { for (int q = 0; q < T.n_tri; q++) if (T.tri_code[q] == code) hp = T.tri_w[q] * A.scale[u + 2]; if (hp < 0.0) hp = sm.hpw[u] * tau; }
               else if (u == 4) { for (int q = 0; q < T.n_tetra; q++) if (T.tetra_code[q] == code) hp = T.tetra_w[q] * A.scale[u + 2]; }
               else { for (int q = 0; q < T.n_hexa; q++) if (T.hexa_code[q] == code) hp = T.hexa_w[q] * A.scale[u + 2]; }
-              if (hp < 0.0) hp = sm.hpw[u] * sm.mmH[ij];
+              if (hp < 0.0) hp = sm.hpw[u] * wH;
             } else {
-              hp = sm.hpw[u] * sm.mmH[ij];
+              hp = sm.hpw[u] * wH;
             }
-            qb = hp + aE + aX + aG * sm.mmI[ij];
-            qb += sm.dring[((d - 2) & 3) * RS + i + 1] * eMLc * eMLi * tau *
-                  sm.mmM[rtype_of(t) * 16 + sm.S[j - 1] * 4 + sm.S[i + 1]] * sc2;
-            info = (rtype_of(t) << 4) | (sm.S[j + 1] << 2) | sm.S[i - 1];
+            qb = hp + aE + aX + aG * wI;
+            qb += dprev * eMLc * eMLi * tau * wMc * sc2;
           }
-          sm.qbi[(d & 31) * RS + i] = qb * sm.mmI[info];
+          sm.qbi[(d & 31) * RS + i] = qb * wInfo;
           sm.info[(d & 31) * RS + i] = (unsigned char)info;
-          double ext = 0.0, stem = 0.0;
-          if (t) {
-            double me, mm;
-            if (i > 1 && j < n) { me = sm.mmExt[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]; mm = sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]; }
-            else if (i > 1) { me = mm = sm.d5[t * 4 + sm.S[i - 1]]; }
-            else if (j < n) { me = mm = sm.d3[t * 4 + sm.S[j + 1]]; }
-            else { me = mm = 1.0; }
-            ext = qb * tau * me;
-            stem = qb * eMLi * tau * mm;
-          }
-          QEXT[j * ld + i] = ext;
-          const int pp = (d - 1) & 1;
-          const double m1 = sm.qm1row[pp][i] * b1 + stem;
-          const double U = b1 * (sm.qm1row[pp][i + 1] + sm.urow[pp][i + 1]);
+          const double me = (i > 1 && j < n) ? wExt : i > 1 ? w5 : j < n ? w3 : 1.0;
+          const double mm = (i > 1 && j < n) ? wMs : i > 1 ? w5 : j < n ? w3 : 1.0;
+          const double ext = t ? qb * tau * me : 0.0, stem = t ? qb * eMLi * tau * mm : 0.0;
+          const double m1 = m1p * b1 + stem;
+          const double U = b1 * (m1q + up);
           sm.qm1row[par][i] = m1;
           sm.urow[par][i] = U;
           sm.dring[(d & 3) * RS + i] = aK;
+          QEXT[j * ld + i] = ext;
           QM1[d * ld + i] = m1;
           QM[d * ld + i] = m1 + aK + U;
           if (hm) { st_agent(&XQM1[d * ld + i], m1); st_agent(&XQM[d * ld + i], m1 + aK + U); }
         }
       }
-      if (hm && k >= KDF0 && k < n) {
-        // far sums of the next diagonal (k), one step ahead: loaded only once the helper's flag shows them published
-        if (flag_ge(__builtin_amdgcn_readfirstlane(fbv), A.hbase + k)) {
-          const int ic = tid + 1 - (k >> 1) - off0;
-          dfar_next = (ic >= 1 && ic <= n - k) ? ld_agent(&DFAR[k * ld + ic]) : 0.0;
-        } else dfar_pending = true;
+      TLMARK2(1, k);
+      if (job_pl) {
+        int* dst = sm.plist[(k + 1) & 1];
+        dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
+        if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = pl3;
+        if (lane == 0) { sm.pcnt[(k + 1) & 1] = pl_cnt; sm.qhead[(k + 1) & 1] = 0; }
       }
-      // side jobs of the step, one finalize wave each (when there are that many): tower table of diagonal k+1,
-      // pairable list of diagonal k+1, exterior column j = k-3 (its cells were stored in step <= k-3 and drained by
-      // that step's barrier)
-      if (!(DRNA_SKIP & 32) && k + 1 < n) {
-        if (wave == w_pl) {
-          const int32_t* row = PL + (k + 1) * ld;
-          const int cnt = row[ld - 1];
-          const int p0 = row[lane], p1 = row[lane + WAVE], p2 = row[lane + 2 * WAVE], p3 = row[min(lane + 3 * WAVE, ld - 1)];
-          int* dst = sm.plist[(k + 1) & 1];
-          dst[lane] = p0; dst[lane + WAVE] = p1; dst[lane + 2 * WAVE] = p2;
-          if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = p3;
-          if (lane == 0) { sm.pcnt[(k + 1) & 1] = cnt; sm.qhead[(k + 1) & 1] = 0; }
-        }
+      if (job_q5) {
+        // q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j): four strided terms per lane, fixed-order wave sum
+        const int j = k - 3, top = j - TURN - 1;
+        double sq = 0.0;
+        if (lane + 1 <= top) sq += sm.q5[lane] * qx0;
+        if (lane + 1 + WAVE <= top) sq += sm.q5[lane + WAVE] * qx1;
+        if (lane + 1 + 2 * WAVE <= top) sq += sm.q5[lane + 2 * WAVE] * qx2;
+        if (lane + 1 + 3 * WAVE <= top) sq += sm.q5[lane + 3 * WAVE] * qx3;
+        sq = wave_sum_f64(sq);
+        sm.q5[j] = sm.q5[j - 1] * sc1 + sq;      // every lane stores the same value
       }
-      if (!(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2) pf_q5_column<NT>(sm, QEXT, ld, k - 3, lane, sc1);
       STAMP(4);
+      TLMARK(1, k);
       if (!(DRNA_SKIP & 128) && k < n && ((DRNA_JOIN_MASK >> wave) & 1)) run_items(k);          // help the sweep of diagonal k
+      TLMARK(2, k);
+      if (hm) { dfar_next = d_req; fb_last = __builtin_amdgcn_readfirstlane(f_req); }
 #ifdef DRNA_PF_LDSBAR
       stores_in_flight<DRNA_PF_LDSBAR>();
       lds_barrier();
@@ -758,6 +806,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
 #pragma unroll
     for (int q = 0; q < TSL; q++) { GE[q] = 0.0; if (TWO_PAR) GO[q] = 0.0; }
     for (int k = TURN + 1; k <= n; k++) {
+      TLMARK(0, k);
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
@@ -778,8 +827,10 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
           }
         }
         STAMP(0);
+        TLMARK(1, k);
         run_items(d);
         STAMP(6);
+        TLMARK(2, k);
       }
 #ifdef DRNA_PF_LDSBAR
       lds_barrier();

@@ -1,0 +1,35 @@
+"""Diagnostic (GPU box): per-wave timeline of the PF LDS kernel's main workgroup of sequence 0, from a -DDRNA_TL build in
+build/var/lib_tl.so (tools/build_variants.sh tl "-DDRNA_TL").  Per step and wave: 100 MHz clock at barrier exit, after the
+finalize / tower step, after the last item.  Prints averages over step ranges in microseconds."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from desirna_amd import engine as E
+import bench
+tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = 64
+rng = np.random.default_rng(20260101)
+seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
+lib = os.path.join(ROOT, "build", "var", "lib_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "tl"))
+eng = E.Engine(max_R=R, max_L=L, lib=lib)
+eng.set_targets([tg])
+for _ in range(3):
+    eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF)
+print(eng.last_timing())
+ld = L + 2; tab = ld * ld
+eng._L.drna_debug_read_pf_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+buf = np.zeros(16 * 3 * 256 + 4 * 3 * 256, dtype=np.float64)
+eng._L.drna_debug_read_pf_ws(eng._h, 4 * tab + tab // 2, buf.size, buf.ctypes.data)
+t = buf.view(np.int64)[:16 * 3 * 256].reshape(16, 3, 256).astype(np.float64) / 100.0      # microseconds
+t2 = buf.view(np.int64)[16 * 3 * 256:].reshape(4, 3, 256).astype(np.float64) / 100.0
+for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
+    ks = np.arange(lo, hi)
+    t0 = t[:, 0, ks].min(axis=0)                      # first wave out of the barrier
+    step = np.diff(t[0, 0, lo:hi + 1]).mean()
+    print("steps %3d..%3d: step %.2f us" % (lo, hi, step))
+    for w in range(16):
+        a = (t[w, 0, ks] - t0).mean(); b = (t[w, 1, ks] - t0).mean(); c = (t[w, 2, ks] - t0).mean()
+        extra = ""
+        if w < 4:
+            extra = "   [requests issued +%.2f  cells finalized +%.2f]" % ((t2[w, 0, ks] - t0).mean(), (t2[w, 1, ks] - t0).mean())
+        print("   wave %2d: out of barrier +%.2f  own job done +%.2f  items done +%.2f%s" % (w, a, b, c, extra))
