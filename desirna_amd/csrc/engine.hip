@@ -478,6 +478,14 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // every stream of the engine is idle here (each call drains them before it returns), so nothing has to be fenced at the
   // start; the two folds run side by side on disjoint CUs and a launch costs ~10 us, so the one that took longer in the
   // previous call is enqueued first
+  // with a helper workgroup per sequence, E(targets) is evaluated by the helpers inside the partition-function launch
+  const bool ev_in_pf = want_ev && pf_help;
+  auto make_eval_args = [&]() {
+    EvalArgs a{};
+    a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
+    a.seqs = d_seqs; a.pt = e->d_pt; a.L = L; a.n_targets = e->n_targets; a.Ed = d_Ed;
+    return a;
+  };
   auto enqueue_pf = [&]() -> int {
     PfArgs a;
     a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
@@ -489,9 +497,9 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
     else if (pf_help) {
       a.helper = 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12);
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a);
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
     } else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a);
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{});
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
     else launch_pf<1024>(a, R, e->s_pf);
@@ -540,9 +548,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   hipStream_t s_ev = e->s_eval;
   if (want_ev && want_mfe && want_pf) s_ev = mfe_first ? e->s_pf : e->s_mfe;
   auto enqueue_eval = [&]() -> int {
-    EvalArgs a;
-    a.T = e->d_mfeT; a.hp_len = e->d_hp_len; a.bulge_len = e->d_bulge_len; a.int_len = e->d_int_len;
-    a.seqs = d_seqs; a.pt = e->d_pt; a.L = L; a.n_targets = e->n_targets; a.Ed = d_Ed;
+    if (ev_in_pf) return DRNA_OK;
+    EvalArgs a = make_eval_args();
     HIP_TRY(hipEventRecord(e->ev_e0, s_ev));
     hipLaunchKernelGGL(eval_kernel, dim3(R * e->n_targets), dim3(WAVE), 0, s_ev, a);
     HIP_TRY(hipGetLastError());
@@ -557,20 +564,29 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   if (want_ev && s_ev == e->s_eval) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
   // join on the host: the streams are drained one after the other (a device-side join -- stream-wait-event packets
   // plus an end marker -- costs ~15 us after the last kernel); "total" = first start event to the latest end event
-  if (want_ev && s_ev == e->s_eval) HIP_TRY(hipStreamSynchronize(e->s_eval));
-  if (mfe_first && want_pf) HIP_TRY(hipStreamSynchronize(e->s_pf));
-  if (want_mfe) HIP_TRY(hipStreamSynchronize(e->s_mfe));
-  if (!mfe_first && want_pf) HIP_TRY(hipStreamSynchronize(e->s_pf));
+#ifdef DRNA_SPINWAIT
+  auto drain = [&](hipStream_t st) -> hipError_t {       // poll instead of the runtime's blocking wait
+    hipError_t q;
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady) { }
+    return q;
+  };
+#else
+  auto drain = [&](hipStream_t st) -> hipError_t { return hipStreamSynchronize(st); };
+#endif
+  if (want_ev && !ev_in_pf && s_ev == e->s_eval) HIP_TRY(drain(e->s_eval));
+  if (mfe_first && want_pf) HIP_TRY(drain(e->s_pf));
+  if (want_mfe) HIP_TRY(drain(e->s_mfe));
+  if (!mfe_first && want_pf) HIP_TRY(drain(e->s_pf));
   e->timing[0] = e->timing[1] = e->timing[2] = 0.f;
   if (want_mfe) HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
   if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
-  if (want_ev) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
+  if (want_ev && !ev_in_pf) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
   {
     hipEvent_t first = mfe_first ? e->ev_m0 : want_pf ? e->ev_p0 : e->ev_e0;
     float t = 0.f, tot = 0.f;
     if (want_mfe) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_m1)); tot = t > tot ? t : tot; }
     if (want_pf) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_p1)); tot = t > tot ? t : tot; }
-    if (want_ev) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_e1)); tot = t > tot ? t : tot; }
+    if (want_ev && !ev_in_pf) { HIP_TRY(hipEventElapsedTime(&t, first, e->ev_e1)); tot = t > tot ? t : tot; }
     e->timing[3] = tot;
     for (int k = 0; k < 4; k++) e->timing_sum[k] += e->timing[k];
     e->timing_sum[4] += 1.0;
@@ -935,7 +951,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     }
     if (nA) {
       a.rg.idx = d_idxA;
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_pf, a);
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_pf, a, EvalArgs{});
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));

@@ -147,13 +147,12 @@ __device__ inline int eval_loop(const EvalSmem& sm, const EvalArgs& A, int i, in
   return T.MLclosing + T.MLintern + (tc > 2 ? T.TermAU : 0) + eval_mm(T.mmM, tc, sj1, si1) + unp * T.MLbase + e_stems;
 }
 
-// grid = R * n_targets workgroups of one wave
-__global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
-  __shared__ EvalSmem sm;
+// one (sequence, structure) evaluation by one wave; `sm` is that wave's own (the wave synchronises its LDS traffic itself, so
+// this also runs inside a larger workgroup: the helper workgroups of pf_lds_kernel evaluate their sequence while they wait for
+// the first rows of the fill)
+__device__ __forceinline__ void eval_one(EvalSmem& sm, EvalArgs A, int r, int k, int lane) {
   const MfeTables& T = *A.T;
-  const int lane = threadIdx.x;
   const bool ragged = A.rg.len != nullptr;
-  const int r = ragged ? blockIdx.x : blockIdx.x / A.n_targets, k = ragged ? 0 : blockIdx.x % A.n_targets;
   if (ragged) A.L = A.rg.len[r];
   const int n = A.L;
   const char* seq = A.seqs + (ragged ? (long long)A.rg.off[r] : (long long)r * n);
@@ -165,9 +164,9 @@ __global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
     sm.S[x + 1] = (unsigned char)(c < 0 ? 0 : c);
   }
   for (int x = lane; x < n + 2; x += WAVE) sm.pt[x] = pt[x];
-  __syncthreads();
+  wave_lds_sync();
   if (lane == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; }
-  __syncthreads();
+  wave_lds_sync();
   int e = 0;
   for (int i = lane + 1; i <= n; i += WAVE)
     if (sm.pt[i] > i) e += eval_loop(sm, A, i, sm.pt[i]);
@@ -188,6 +187,14 @@ __global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
   e = wave_sum_i32(e);
   const unsigned long long anybad = __ballot(bad);
   if (lane == 0) A.Ed[ragged ? (long long)r : (long long)r * A.n_targets + k] = anybad ? INF_REF : e;
+  wave_lds_sync();                         // the wave may reuse sm for its next structure
+}
+
+// grid = R * n_targets workgroups of one wave
+__global__ __launch_bounds__(WAVE) void eval_kernel(EvalArgs A) {
+  __shared__ EvalSmem sm;
+  const bool ragged = A.rg.len != nullptr;
+  eval_one(sm, A, ragged ? blockIdx.x : blockIdx.x / A.n_targets, ragged ? 0 : blockIdx.x % A.n_targets, threadIdx.x);
 }
 
 }  // namespace drna

@@ -19,6 +19,7 @@
 #define DRNA_JOIN_MASK 0xF     // finalize waves that join the sweep's work queue once their own step is done
 #endif
 #include <cstddef>
+#include "eval_structure.hpp"
 #include "fold_pf.hpp"
 
 namespace drna {
@@ -307,7 +308,7 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 // KLAG steps after the last of them, so the helper works KROUND diagonals per round (enough items for sixteen waves, one set
 // of barriers) and stays ahead of the main workgroup's need by itself.  Results travel back through DFAR (table 5).
 template <int NT>
-__device__ void pf_kfar_helper(const PfArgs& A, PfFastSmem<NT>& sm, int r, int n) {
+__device__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& EV, PfFastSmem<NT>& sm, int r, int n) {
   constexpr int NW = NT / WAVE;
   const int ld = A.ld, tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
@@ -321,6 +322,14 @@ __device__ void pf_kfar_helper(const PfArgs& A, PfFastSmem<NT>& sm, int r, int n
   int* ctl = reinterpret_cast<int*>(part + KROUND * 4 * 256);
   for (int k = tid; k < KROUND * 4 * 256; k += NT) part[k] = 0.0;
   if (tid == 0) ctl[0] = 0;
+  // E(target structures) of this sequence (eval_structure.hpp), while the main workgroup works towards the first far split point:
+  // a launch of its own would need CUs of its own, and in the batches that get a helper every CU holds a fold workgroup
+  if (EV.n_targets > 0) {
+    constexpr int NEV = NW < 8 ? NW : 8;
+    EvalSmem* es = reinterpret_cast<EvalSmem*>(ctl + 32);
+    if (wave < NEV)
+      for (int k = wave; k < EV.n_targets; k += NEV) eval_one(es[wave], EV, r, k, lane);
+  }
   __syncthreads();
   for (int d0 = KDF0; d0 < n; d0 += KROUND) {
     const int dmax = min(d0 + KROUND - 1, n - 1);
@@ -367,7 +376,7 @@ __device__ void pf_kfar_helper(const PfArgs& A, PfFastSmem<NT>& sm, int r, int n
 }
 
 template <int NT>
-__device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
+__device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const EvalArgs& EV) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
@@ -376,7 +385,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
   const int r = A.rg.idx ? A.rg.idx[bx] : bx;
   if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
-  if (hm && (blockIdx.x & 1)) { pf_kfar_helper<NT>(A, sm, r, n); return; }
+  if (hm && (blockIdx.x & 1)) { pf_kfar_helper<NT>(A, EV, sm, r, n); return; }
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
 
@@ -704,9 +713,13 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
           // every producer writes its slot of every live cell on every diagonal it exists for, so nothing is zeroed here:
           // a family that does not exist yet (or a cell that cannot pair) is simply not read
           const int j = i + d;
-          const int si = sm.S[i], sj = sm.S[j], si1 = sm.S[i + 1], sj1 = sm.S[j - 1], sim = sm.S[i - 1], sjp = sm.S[j + 1];
-          const double aG = d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
-          const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
+#ifndef DRNA_FVAR
+#define DRNA_FVAR 0      // diagnostic builds only (timing; results wrong): 1 no global stores, 2 no table lookups, 4 no sequence reads, 8 no partial-sum reads
+#endif
+          const int si = (DRNA_FVAR & 4) ? 2 : sm.S[i], sj = (DRNA_FVAR & 4) ? 1 : sm.S[j], si1 = (DRNA_FVAR & 4) ? 0 : sm.S[i + 1],
+                    sj1 = (DRNA_FVAR & 4) ? 3 : sm.S[j - 1], sim = (DRNA_FVAR & 4) ? 1 : sm.S[i - 1], sjp = (DRNA_FVAR & 4) ? 2 : sm.S[j + 1];
+          const double aG = (DRNA_FVAR & 8) ? 1e-3 : d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
+          const double aKn = (DRNA_FVAR & 8) ? 1e-3 : d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
           double aKf = 0.0;
           if (hm) aKf = dfar_cur;
           else if (d >= KDF0) {                    // ((p0 + p1) + p2) + p3 with the sub-sums that exist (the others count as zero)
@@ -720,11 +733,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
           const double tau = t > 2 ? eTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
-          const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
-          const double wH = sm.mmH[ij], wI = sm.mmI[ij], wMc = sm.mmM[rt * 16 + sj1 * 4 + si1], wInfo = sm.mmI[info];
+          const double aE = (DRNA_FVAR & 8) ? 1e-3 : sm.accE[par][tid], aX = (DRNA_FVAR & 8) ? 1e-3 : (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
+          const double wH = (DRNA_FVAR & 2) ? 0.5 : sm.mmH[ij], wI = (DRNA_FVAR & 2) ? 0.5 : sm.mmI[ij], wMc = (DRNA_FVAR & 2) ? 0.5 : sm.mmM[rt * 16 + sj1 * 4 + si1], wInfo = (DRNA_FVAR & 2) ? 0.5 : sm.mmI[info];
           const double dprev = sm.dring[((d - 2) & 3) * RS + i + 1];
           const int ex = t * 16 + sim * 4 + sjp;
-          const double wExt = sm.mmExt[ex], wMs = sm.mmM[ex], w5 = sm.d5[t * 4 + sim], w3 = sm.d3[t * 4 + sjp];
+          const double wExt = (DRNA_FVAR & 2) ? 0.5 : sm.mmExt[ex], wMs = (DRNA_FVAR & 2) ? 0.5 : sm.mmM[ex], w5 = (DRNA_FVAR & 2) ? 0.5 : sm.d5[t * 4 + sim], w3 = (DRNA_FVAR & 2) ? 0.5 : sm.d3[t * 4 + sjp];
           const int pp = (d - 1) & 1;
           const double m1p = sm.qm1row[pp][i], m1q = sm.qm1row[pp][i + 1], up = sm.urow[pp][i + 1];
           double qb = 0.0;
@@ -757,10 +770,12 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
           sm.qm1row[par][i] = m1;
           sm.urow[par][i] = U;
           sm.dring[(d & 3) * RS + i] = aK;
-          QEXT[j * ld + i] = ext;
-          QM1[d * ld + i] = m1;
-          QM[d * ld + i] = m1 + aK + U;
-          if (hm) { st_agent(&XQM1[d * ld + i], m1); st_agent(&XQM[d * ld + i], m1 + aK + U); }
+          if (!(DRNA_FVAR & 1)) {
+            QEXT[j * ld + i] = ext;
+            QM1[d * ld + i] = m1;
+            QM[d * ld + i] = m1 + aK + U;
+            if (hm) { st_agent(&XQM1[d * ld + i], m1); st_agent(&XQM[d * ld + i], m1 + aK + U); }
+          }
         }
       }
       TLMARK2(1, k);
@@ -867,9 +882,9 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A) {
+__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A, EvalArgs EV) {      // EV.n_targets > 0 (helper launches only): E(targets) too
   __shared__ PfFastSmem<NT> sm;
-  pf_lds_body<NT>(sm, A);
+  pf_lds_body<NT>(sm, A, EV);
 }
 
 }  // namespace drna

@@ -203,15 +203,15 @@ int emu_pf(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int
       if (nt == 64) pf_kernel<64>(a);
       else if (nt == 128) pf_kernel<128>(a);
       else if (nt == 256) pf_kernel<256>(a);
-      else if (nt == -256 || nt == -257) pf_lds_kernel<256>(a);
-      else pf_lds_kernel<1024>(a);
+      else if (nt == -256 || nt == -257) pf_lds_kernel<256>(a, EvalArgs{});
+      else pf_lds_kernel<1024>(a, EvalArgs{});
     };
     if (helper) {           // two workgroups side by side, each with an LDS image of its own
       auto* s256 = new PfFastSmem<256>[2];
       auto* s1024 = new PfFastSmem<1024>[2];
       std::vector<std::function<void()>> fns;
       for (int b = 0; b < 2; b++)
-        fns.push_back([&, b]() { if (nt == -257) pf_lds_body<256>(s256[b], a); else pf_lds_body<1024>(s1024[b], a); });
+        fns.push_back([&, b]() { if (nt == -257) pf_lds_body<256>(s256[b], a, EvalArgs{}); else pf_lds_body<1024>(s1024[b], a, EvalArgs{}); });
       emu_launch_many(2 * r, nt == -257 ? 256 : 1024, fns);
       delete[] s256; delete[] s1024;
     } else emu_launch(r, nt < 0 ? -nt : nt, fn);
@@ -295,7 +295,7 @@ int emu_ragged(const int32_t* blob, int n_int32, int R, int max_L, const int32_t
     b.rg.len = lens; b.rg.off = offs;
     if (lds) {
       emu_launch(r, 256, [&]() { mfe_lds_kernel<256>(a); });
-      emu_launch(r, 256, [&]() { pf_lds_kernel<256>(b); });
+      emu_launch(r, 256, [&]() { pf_lds_kernel<256>(b, EvalArgs{}); });
     } else {
       emu_launch(r, 128, [&]() { mfe_kernel<128>(a); });
       emu_launch(r, 128, [&]() { pf_kernel<128>(b); });
