@@ -55,8 +55,7 @@ struct PfFastSmem {
   double rbul[128];               // expTermAU(inner type) / expMismatchI(info)
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
-  double eW[128];                 // E items: size weight (x scale) of shape slot x (0..63 bulges, 64..127 1xn loops; padding 0)
-  int eshape[128];                // s = u1+u2 | u1 << 8 of the slot
+  double eWt[36][2];              // E items, by loop size t: {bulge[t] scale[t+2], interior[t] eninio[t-2] scale[t+2] (1xn loops, t >= 4)}; 0 beyond 30
   double xc[8];                   // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items)
   double twc[32][2];              // by total size s of a generic loop: {eninio[s - 4], interior[s] scale[s + 2] (0 below s = 6)}
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
@@ -413,26 +412,9 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
   for (int k = tid; k <= n; k += NT) sm.hpw[k] = A.hp_w[k];
-  for (int x = tid; x < 128; x += NT) {
-    // E items: a 16-lane row works on one pairable cell; lane l of the row takes the eight shape slots 16 k + l: slots < 64
-    // bulges (x < 29: (0,u) u = x+2; x < 58: (u,0) u = x-27), slots >= 64 1xn loops (y = x-64 < 27: (1,u) u = y+3; y < 54:
-    // (u,1) u = y-24); the remaining slots are padding with weight 0
-    int s_, u1_;
-    double W = 0.0;
-    if (x < 64) {
-      const bool on = x < 58;
-      u1_ = (x < 29 || !on) ? 0 : x - 27;
-      s_ = !on ? 2 : x < 29 ? x + 2 : x - 27;
-      if (on) W = T.bulge[s_] * A.scale[s_ + 2];
-    } else {
-      const int y = x - 64;
-      const bool on = y < 54;
-      u1_ = (y < 27 || !on) ? 1 : y - 24;
-      s_ = !on ? 4 : y < 27 ? y + 4 : y - 23;
-      if (on) W = T.interior[s_] * T.eninio[s_ - 2] * A.scale[s_ + 2];
-    }
-    sm.eshape[x] = s_ | (u1_ << 8);
-    sm.eW[x] = W;
+  for (int t = tid; t < 36; t += NT) {
+    sm.eWt[t][0] = t >= 2 && t <= 30 ? T.bulge[t] * A.scale[t + 2] : 0.0;
+    sm.eWt[t][1] = t >= 4 && t <= 30 ? T.interior[t] * T.eninio[t - 2] * A.scale[t + 2] : 0.0;
   }
   if (tid == 0) {
     sm.xc[0] = T.bulge[1] * A.scale[3]; sm.xc[1] = T.interior[5] * T.eninio[1] * A.scale[7];
@@ -579,34 +561,26 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           if (act1) sm.partK[par][row][i + 1 + slot0] = v1;
         }
       } else if (it < nK + nE) {
-        // ---- E: four pairable cells per item, one per 16-lane row; a lane folds its eight shape slots (two staged halves:
-        // bulges, then 1xn loops; shapes whose inner pair would be too short read the zero row), the row sum takes four DPP
-        // steps for all four cells at once, lane 15 of each row is the only writer
+        // ---- E: four pairable cells per item, one per 16-lane row.  Lane l of a row takes the loop SIZES t = l + 2 and l + 18
+        // (2 .. 30): the two bulges (0,t) (t,0) and the two 1xn loops (1,t-1) (t-1,1) of one size have their inner pairs on
+        // ONE ring row, d - 2 - t, at columns i+1, i+t+1 and i+2, i+t -- one row address and two pairs of adjacent cells per
+        // size instead of four separately decoded shape slots, and the size weights come straight from a table indexed by
+        // the lane (no per-slot shape words).  Row sums by four DPP steps for all four cells at once, lane 15 of a row writes.
         const int q = 4 * (it - nK) + (lane >> 4);
         const int pe = sm.plist[par][q < pcnt ? q : pcnt - 1];
         const int i0 = pe & 255, ij = pe >> 8;
-        double acc[2];
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          int sh[4], off[4], f[4];
-          double w[4], rr[4], ww[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) { sh[k] = sm.eshape[half * 64 + k * 16 + (lane & 15)]; ww[k] = sm.eW[half * 64 + k * 16 + (lane & 15)]; }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int dp = d - 2 - (sh[k] & 255);                // diagonal of the inner pair
-            off[k] = (dp & 31) * RS + 1 + (sh[k] >> 8) + i0;             // rows of diagonals <= TURN read as zero
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) { w[k] = sm.qbi[off[k]]; f[k] = sm.info[off[k]]; }
-#pragma unroll
-          for (int k = 0; k < 4; k++) rr[k] = half ? sm.r1n[f[k]] : sm.rbul[f[k]];
-          double a = 0.0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) a += w[k] * rr[k] * ww[k];
-          acc[half] = a;
-        }
-        double v = acc[0] * ((ij >> 4) > 2 ? eTau : 1.0) + acc[1] * sm.mm1n[ij];
+        const int tA = (lane & 15) + 2, tBr = tA + 16, tB = tBr > 30 ? 30 : tBr;      // sizes beyond 30 weigh nothing (eWt) and read size 30's cells
+        const f64x2 wA = *reinterpret_cast<const f64x2*>(&sm.eWt[tA][0]), wB = *reinterpret_cast<const f64x2*>(&sm.eWt[tBr][0]);
+        const int oA = ((d - 2 - tA) & 31) * RS + i0, oB = ((d - 2 - tB) & 31) * RS + i0;   // rows of diagonals <= TURN read as zero
+        const double a1 = sm.qbi[oA + 1], a2 = sm.qbi[oA + 2], a3 = sm.qbi[oA + tA], a4 = sm.qbi[oA + tA + 1];
+        const double b1_ = sm.qbi[oB + 1], b2_ = sm.qbi[oB + 2], b3_ = sm.qbi[oB + tB], b4_ = sm.qbi[oB + tB + 1];
+        const int fa1 = sm.info[oA + 1], fa2 = sm.info[oA + 2], fa3 = sm.info[oA + tA], fa4 = sm.info[oA + tA + 1];
+        const int fb1 = sm.info[oB + 1], fb2 = sm.info[oB + 2], fb3 = sm.info[oB + tB], fb4 = sm.info[oB + tB + 1];
+        const double ra1 = sm.rbul[fa1], ra4 = sm.rbul[fa4], ra2 = sm.r1n[fa2], ra3 = sm.r1n[fa3];
+        const double rb1 = sm.rbul[fb1], rb4 = sm.rbul[fb4], rb2 = sm.r1n[fb2], rb3 = sm.r1n[fb3];
+        const double bul = (a1 * ra1 + a4 * ra4) * wA.x + (b1_ * rb1 + b4_ * rb4) * wB.x;
+        const double one = (a2 * ra2 + a3 * ra3) * wA.y + (b2_ * rb2 + b3_ * rb3) * wB.y;
+        double v = bul * ((ij >> 4) > 2 ? eTau : 1.0) + one * sm.mm1n[ij];
         v = dpp_add_f64<0x111, 0xF>(v);
         v = dpp_add_f64<0x112, 0xF>(v);
         v = dpp_add_f64<0x114, 0xF>(v);
