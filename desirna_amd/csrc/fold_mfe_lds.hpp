@@ -88,6 +88,13 @@ struct FmlLds {
 #else
 #define STAMP(k) do { } while (0)
 #endif
+// -DDRNA_TL -DDRNA_FIN_SYNC (tools/timeline.py mfe): raw 100 MHz clocks per wave and step of sequence 0's main workgroup, into
+// the unused table 2 of its workspace: 0 after the barrier, 1 after the finalize / tower step, 2 after the last item
+#ifdef DRNA_TL
+#define MTLMARK(ev, k) do { if (mtl_on && lane == 0) mtl[((wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define MTLMARK(ev, k) do { } while (0)
+#endif
 
 // exterior column j: f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + E_ExtLoop); one wave, every lane stores the same value
 template <int NT>
@@ -586,6 +593,10 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
 #endif
+#ifdef DRNA_TL
+  long long* mtl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
+  const bool mtl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0;
+#endif
   PCLK(3);
   if (aw < 0) {
     // ================= finalize waves
@@ -596,15 +607,30 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     int32_t* const xf = xw + (MFE_FAST_NMAX + 2) * XP;
     const int32_t* const xk = reinterpret_cast<const int32_t*>(lk.xb);
     const int32_t* const xi = xk + (MFE_FAST_NMAX + 2) * XP;
-    int pfK = INF, pfI = INF, fbv = 0;
+    int pfK = INF, pfI = INF, fb_s = 0;
     bool have = false;
-    if (DUAL) fbv = ld_agent(lk.flagB);
+    if (DUAL) fb_s = __builtin_amdgcn_readfirstlane(ld_agent(lk.flagB));
     DDBG(if (tid == 0) lk.dbg[2] -= clock64());
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
-      // rows of diagonal d-1: stored in step k-1 and landed before its barrier (counted wait: in the two-workgroup kernel only
-      // the three fetch-ahead loads stay in flight)
-      if (DUAL && tid == 0 && d - 1 > TURN) st_agent(lk.flagA, lk.base + d - 1);
+      MTLMARK(0, k);
+      // rows of diagonal d-2: stored in step k-2, and a step's stores have landed by the NEXT step's barrier (the counted wait
+      // at the end of a step leaves that step's own stores in flight: no store latency inside a step)
+      if (DUAL && tid == 0 && d - 2 > TURN) st_agent(lk.flagA, lk.base + d - 2);
+      // two-workgroup kernel: the helper's results for diagonal d+1 and its flag are REQUESTED here, before this step's stores
+      // (vector-memory operations retire in order), and taken over at the end of the step
+      int rqK = INF, rqI = INF, rqF = 0;
+      bool rq_have = false, rq_on = false;
+      if (DUAL && d > TURN) {
+        const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
+        rq_have = d + 1 < n && flag_ge(fb_s, lk.base + d + 1);
+        rq_on = rq_have && i2 >= 1 && i2 <= n - d - 1;
+#ifndef DRNA_DBG_NOPF
+        rqK = ld_agent(rq_on ? xk + (d + 1) * XP + i2 : lk.flagB);
+        rqI = ld_agent(rq_on ? xi + (d + 1) * XP + i2 : lk.flagB);
+#endif
+        rqF = ld_agent(lk.flagB);
+      }
       // ---- top of the step: requests of the pipelined side jobs
       // (the list row of diagonal k+1 and the exterior column's cells are requested here and consumed after the cell
       // finalize, so that their L2 round trip overlaps it)
@@ -713,11 +739,12 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           const int i = lane + 1 + c * WAVE;
           if (i <= j - TURN - 1 && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
         }
-        m = wave_min_i32(m);
+        m = wave_min_i32_lane63(m);        // DPP (no LDS traffic); lane 63 holds the minimum
         const int prev = sm.f5[j - 1];
-        sm.f5[j] = prev < m ? prev : m;
+        if (lane == WAVE - 1) sm.f5[j] = prev < m ? prev : m;
       }
       STAMP(4);
+      MTLMARK(1, k); MTLMARK(2, k);
       DDBG(if (tid == 0) lk.dbg[3] -= clock64());
       // every global load of the step has been consumed; what is still in flight are this step's stores (c, exterior term,
       // and the two published words of the two-workgroup kernel): the wait lets exactly those stay in flight across the
@@ -726,21 +753,16 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 #ifdef DRNA_FIN_SYNC
       __syncthreads();
 #else
+      bool stored = false;
+      if (d > TURN) { const int i_ = tid + 1 - (d >> 1) - off0; stored = __ballot(i_ >= 1 && i_ <= n - d) != 0ull; }
       if (DUAL && d > TURN) {
-        // fetch ahead for diagonal d+1 if the flag value read one step ago covers it, and read the flag again for the next
-        // step: always three loads, the last memory operations of the step, left in flight across the barrier
-        const int ncell = n - d;
-        const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
-        have = d + 1 < n && flag_ge(__builtin_amdgcn_readfirstlane(fbv), lk.base + d + 1);
-        const bool on2 = have && i2 >= 1 && i2 <= ncell - 1;
-#ifndef DRNA_DBG_NOPF
-        pfK = ld_agent(on2 ? xk + (d + 1) * XP + i2 : lk.flagB);
-        pfI = ld_agent(on2 ? xi + (d + 1) * XP + i2 : lk.flagB);
-        if (!on2) { pfK = INF; pfI = INF; }
-#endif
-        fbv = ld_agent(lk.flagB);
+        pfK = rq_on ? rqK : INF; pfI = rq_on ? rqI : INF;
+        have = rq_have;
+        fb_s = __builtin_amdgcn_readfirstlane(rqF);
       }
-      stores_in_flight<DUAL ? 3 : 2>();
+      // the requests above are older than the stores, so once they are in, everything of the previous steps has landed; this
+      // step's own stores (2, or 4 in the two-workgroup kernel) stay in flight across the barrier
+      if (stored) stores_in_flight<DUAL ? 4 : 2>(); else stores_in_flight<0>();
       DDBG(if (tid == 0) { const long long t = clock64(); lk.dbg[3] += t; lk.dbg[4] -= t; });
       lds_barrier();                       // one barrier per diagonal
 #endif
@@ -756,6 +778,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
     const int item_rank = NB < 3 ? aw : my_tb == 0 ? my_g : my_tb == NB - 1 ? NG + my_g : !pinned ? aw : 2 * NG + (aw - NG);
 
     for (int k = TURN + 1; k <= n; k++) {
+      MTLMARK(0, k);
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
@@ -770,6 +793,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
         }
         STAMP(0);
+        MTLMARK(1, k);
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
         const int slot0 = sh + off0 - 1;          // tower slot of column i is i + slot0
         // ---- floating items of the diagonal, taken from a work queue (LDS counter) so the sweep waves stay
@@ -802,6 +826,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
           }
         }
         STAMP(6);
+        MTLMARK(2, k);
       }
       __syncthreads();
       STAMP(3);

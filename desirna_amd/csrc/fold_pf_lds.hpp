@@ -72,8 +72,9 @@ __device__ __forceinline__ void pf_q5_column(PfFastSmem<NT>& sm, const double* _
                                              double sc1) {
   double s = 0.0;
   for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) s += sm.q5[i - 1] * QEXT[j * ld + i];
-  s = wave_sum_f64(s);
-  sm.q5[j] = sm.q5[j - 1] * sc1 + s;      // every lane stores the same value
+  s = wave_total_f64_lane63(s);            // DPP scan, fixed order; lane 63 holds the total
+  if (lane == WAVE - 1) sm.q5[j] = sm.q5[j - 1] * sc1 + s;
+  wave_lds_sync();                         // the next column of the same wave reads q5[j]
 }
 
 template <class SM>
@@ -767,8 +768,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         if (lane + 1 + WAVE <= top) sq += sm.q5[lane + WAVE] * qx1;
         if (lane + 1 + 2 * WAVE <= top) sq += sm.q5[lane + 2 * WAVE] * qx2;
         if (lane + 1 + 3 * WAVE <= top) sq += sm.q5[lane + 3 * WAVE] * qx3;
-        sq = wave_sum_f64(sq);
-        sm.q5[j] = sm.q5[j - 1] * sc1 + sq;      // every lane stores the same value
+        sq = wave_total_f64_lane63(sq);          // DPP scan (no LDS traffic); lane 63 holds the total
+        if (lane == WAVE - 1) sm.q5[j] = sm.q5[j - 1] * sc1 + sq;
       }
       STAMP(4);
       TLMARK(1, k);

@@ -11,6 +11,7 @@ tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = 64
 rng = np.random.default_rng(20260101)
 seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
 lib = os.path.join(ROOT, "build", "var", "lib_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "tl"))
+MFE = len(sys.argv) > 2 and sys.argv[2] == "mfe"          # the MFE kernel's marks (table 2 of its workspace) instead of the PF kernel's
 eng = E.Engine(max_R=R, max_L=L, lib=lib)
 eng.set_targets([tg])
 for _ in range(3):
@@ -19,7 +20,11 @@ print(eng.last_timing())
 ld = L + 2; tab = ld * ld
 eng._L.drna_debug_read_pf_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
 buf = np.zeros(16 * 3 * 256 + 4 * 3 * 256, dtype=np.float64)
-eng._L.drna_debug_read_pf_ws(eng._h, 4 * tab + tab // 2, buf.size, buf.ctypes.data)
+if MFE:
+    eng._L.drna_debug_read_mfe_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    eng._L.drna_debug_read_mfe_ws(eng._h, 2 * tab, 16 * 3 * 256 * 2, buf.ctypes.data)
+else:
+    eng._L.drna_debug_read_pf_ws(eng._h, 4 * tab + tab // 2, buf.size, buf.ctypes.data)
 t = buf.view(np.int64)[:16 * 3 * 256].reshape(16, 3, 256).astype(np.float64) / 100.0      # microseconds
 t2 = buf.view(np.int64)[16 * 3 * 256:].reshape(4, 3, 256).astype(np.float64) / 100.0
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
@@ -30,6 +35,6 @@ for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     for w in range(16):
         a = (t[w, 0, ks] - t0).mean(); b = (t[w, 1, ks] - t0).mean(); c = (t[w, 2, ks] - t0).mean()
         extra = ""
-        if w < 4:
+        if w < 4 and not MFE:
             extra = "   [requests issued +%.2f  cells finalized +%.2f]" % ((t2[w, 0, ks] - t0).mean(), (t2[w, 1, ks] - t0).mean())
         print("   wave %2d: out of barrier +%.2f  own job done +%.2f  items done +%.2f%s" % (w, a, b, c, extra))
