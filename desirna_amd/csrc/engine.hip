@@ -99,6 +99,7 @@ struct drna_engine {
   int flag_resets = 0;            // times the hand-over flags were zeroed because an epoch neared the compare range
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
   int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
+  bool helper_fault = false;      // tests: the helper workgroups of the partition function leave at once (a lost partner)
   bool pf_helper = true;          // small batches: a helper workgroup per sequence computes the far multiloop split points of the
                                   // partition function (fold_pf_lds.hpp, pf_kfar_helper); option "pf_helper"
   int* d_pflags = nullptr;        // its hand-over flags: per sequence two 128-byte lines
@@ -326,6 +327,7 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   if (!strcmp(name, "pf_helper")) { e->pf_helper = value != 0; return DRNA_OK; }
+  if (!strcmp(name, "helper_fault")) { e->helper_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
   if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; e->pfh_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
@@ -496,7 +498,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
     else if (pf_help) {
-      a.helper = 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12);
+      a.helper = e->helper_fault ? 2 : 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12);
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
     } else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{});
@@ -1396,7 +1398,10 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
   }
   const int nt = e->n_targets;
   std::vector<char> prop((size_t)R * L), pss((size_t)R * L);
-  std::vector<double> pEpf(R), pscore(R), pmcc(R), prec(R), pprec(R);
+  std::vector<double> pEpf(R), pscore(R), pmcc(R), prec(R), pprec(R), pEdef;
+  bool want_edef = false;                  // term 6: ensemble defect against targets[0] (utils/energy_scores.py:362-374,397-398)
+  for (int k = 0; k < n_terms; k++) want_edef |= term_id[k] == 6;
+  if (want_edef) pEdef.resize(R);
   std::vector<int32_t> pEmfe(R), pEd((size_t)R * nt);
   std::vector<unsigned char> acc(R), better(R);
   std::vector<int> pr(L), pq(L);
@@ -1409,6 +1414,10 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
     rc = drna_score_batch(e, R, L, prop.data(), flags | DRNA_NEED_PF | DRNA_NEED_MFE | DRNA_NEED_EVAL, pEpf.data(), pEmfe.data(),
                           pss.data(), pEd.data());
     if (rc != DRNA_OK) return rc;
+    if (want_edef) {                        // inside + outside recursion of every proposal (fold_outside.hpp)
+      rc = drna_ensemble_defect_batch(e, R, L, prop.data(), pEdef.data(), nullptr);
+      if (rc != DRNA_OK) return rc;
+    }
     for (int r = 0; r < R; r++) {
       // SimScore of the proposal's structure against the target (utils/sim_score.py:62-147)
       if (!pair_table(pss.data() + (size_t)r * L, L, pq.data())) { e->err = "drna_mc_run: unbalanced MFE structure from the engine"; return DRNA_ERR_STRUCTURE; }
@@ -1428,7 +1437,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
       const double rec = py_round3((double)tp / ((double)(tp + fn) + 0.001));
       const double pre = py_round3((double)tp / ((double)(tp + fp) + 0.001));
       const double ed = pEd[(size_t)r * nt] / 100.0;
-      // -sf terms (utils/energy_scores.py:376-398): 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall
+      // -sf terms (utils/energy_scores.py:376-398): 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall, 6 Edef
       double tot = 0.0;
       for (int k = 0; k < n_terms; k++) {
         double v;
@@ -1439,6 +1448,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
           case 3: v = ed - pEmfe[r] / 100.0; break;
           case 4: v = (1 - pre) * 10; break;
           case 5: v = (1 - rec) * 10; break;
+          case 6: v = pEdef[r]; break;
           default: e->err = "drna_mc_run: unknown scoring term"; return DRNA_ERR_ARG;
         }
         tot += v * term_w[k];

@@ -77,7 +77,23 @@ __device__ __forceinline__ void stores_in_flight() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-constexpr int SPIN_LIMIT = 1 << 22;   // ~4 s of polling before a wait gives up (ST_SYNC): generous, a partner workgroup may queue behind other work
+// A wait for another workgroup is bounded by TIME (round 3; it was 2^22 polls, about 4 s): HIP promises no dispatch order, so a
+// partner may never have been scheduled, and the engine then redoes the call with one workgroup per fold -- which must not cost
+// seconds.  10 ms of the 100 MHz wall clock is far beyond any legitimate wait (a whole 2046-nt fold by strips takes 35 ms and its
+// strips wait for each other one diagonal at a time) and keeps a lost call in the tens of milliseconds.  The CPU emulation of the
+// kernels (tests/emu) counts polls instead.
+constexpr int SPIN_LIMIT = 1 << 22;
+constexpr long long SPIN_BUDGET_TICKS = 1000000;          // 10 ms at 100 MHz
+struct SpinClock {
+#ifdef DRNA_EMU
+  int n = 0;
+  __device__ __forceinline__ bool expired() { return ++n > SPIN_LIMIT; }
+#else
+  long long t0 = (long long)wall_clock64();
+  int n = 0;
+  __device__ __forceinline__ bool expired() { return (++n & 15) == 0 && (long long)wall_clock64() - t0 > SPIN_BUDGET_TICKS; }
+#endif
+};
 #ifdef DRNA_DUALDBG
 #define DDBG(stmt) do { stmt; } while (0)
 #else
@@ -85,11 +101,12 @@ constexpr int SPIN_LIMIT = 1 << 22;   // ~4 s of polling before a wait gives up 
 #endif
 // all lanes of the calling wave poll the same word (one request); returns false when the wait expired
 __device__ __forceinline__ bool wait_flag_wave(const int* flag, int target) {
-  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+  SpinClock clk;
+  for (;;) {
     if (flag_ge(__builtin_amdgcn_readfirstlane(ld_agent(flag)), target)) return true;
+    if (clk.expired()) return false;
     spin_pause();
   }
-  return false;
 }
 
 // all lanes of the wave have executed their LDS operations up to here (wave-private staging through LDS)
@@ -325,13 +342,14 @@ struct StripRec {              // MFE strips: exchange records and list counts l
 // wait until the strip's flag shows diagonal `target` (or DONE / FAIL); one wave, every lane returns the same value
 __device__ __forceinline__ bool strip_wait(const int* flag, int base, int d, int& seen) {
   const int target = base + d;
-  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+  SpinClock clk;
+  for (;;) {
     const int v = __builtin_amdgcn_readfirstlane(ld_agent(flag));
     seen = v;
     if (flag_ge(v, target)) return v != base + STRIP_FAIL;
+    if (clk.expired()) return false;
     spin_pause();
   }
-  return false;
 }
 
 #if STRIP_DIAG & 8

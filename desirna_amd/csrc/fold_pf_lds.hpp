@@ -385,7 +385,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   const int r = A.rg.idx ? A.rg.idx[bx] : bx;
   if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
-  if (hm && (blockIdx.x & 1)) { pf_kfar_helper<NT>(A, EV, sm, r, n); return; }
+  if (hm && (blockIdx.x & 1)) {
+    if (A.helper == 2) return;                        // fault injection (tests): the helper never shows up, the main workgroup's wait expires
+    pf_kfar_helper<NT>(A, EV, sm, r, n);
+    return;
+  }
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
 
@@ -518,6 +522,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   const int* flagB = hm ? A.hflags + (long long)r * 64 + 32 : nullptr;
   double dfar_cur = 0.0, dfar_next = 0.0;
   int fb_last = 0;                  // (a zero flag never compares as published: epochs start at 1)
+  bool helper_lost = false;
   // Floating work items of diagonal d, taken from a work queue (LDS counter).  The sweep waves run this after their tower
   // step; the finalize waves, which are done with diagonal d-1 long before the sweep of d ends, join in: every item owns
   // its output slots and reads nothing the current step writes, so the result does not depend on who takes it.
@@ -672,9 +677,9 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         f_req = ld_agent(flagB);
         if (k >= KDF0 && k < n) {
           // the flag value of the previous step decides (the helper runs rounds ahead, an old value will do)
-          if (!flag_ge(fb_last, A.hbase + k)) {       // rare: the helper is not a step ahead -- wait here
+          if (!helper_lost && !flag_ge(fb_last, A.hbase + k)) {       // rare: the helper is not a step ahead -- wait here
             int seen = 0;
-            if (!strip_wait(flagB, A.hbase, k, seen)) sm.flag = 2;
+            if (!strip_wait(flagB, A.hbase, k, seen)) { sm.flag = 2; helper_lost = true; }     // one expired wait per wave, then no more
           }
           const int ic = tid + 1 - (k >> 1) - off0;
           d_req = (ic >= 1 && ic <= n - k) ? ld_agent(&DFAR[k * ld + ic]) : 0.0;

@@ -471,7 +471,7 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
     simulation_data = records(0) if keep_records else []
     if native_loop is None:
         native_loop = True
-    native_loop = native_loop and all(name in eng.TERM_IDS for name, _ in sf)   # Edef needs the outside kernel: Python loop
+    native_loop = native_loop and all(name in eng.TERM_IDS for name, _ in sf)   # (every -sf term, Edef included, has a native id)
     cur = np.ascontiguousarray(cur); cur_ss = np.ascontiguousarray(cur_ss)
     cur_score = np.ascontiguousarray(cur_score, dtype=np.float64); cur_mcc = np.ascontiguousarray(cur_mcc, dtype=np.float64)
     cur_epf = np.ascontiguousarray(cur_epf, dtype=np.float64); cur_ed = np.ascontiguousarray(cur_ed, dtype=np.float64)
@@ -538,7 +538,8 @@ def run_design_fast(input_file, replicas=10, exchange=100, steps=None, timelimit
         best = min((b for b in cands.values() if b is not None), key=lambda b: (b["mcc"], b["scoring_function"]))
     stats["elapsed_s"] = time.time() - t_start
     return {"best": SimpleNamespace(**best), "solved": solved, "stats": stats, "steps": step, "simulation_data": simulation_data,
-            "engine": eng, "temps": [float(t) for t in temps], "local": [int(r) for r in local]}
+            "engine": eng, "temps": [float(t) for t in temps], "local": [int(r) for r in local],
+            "used_native_loop": bool(native_loop)}
 
 
 def run_puzzle_set(inputs, rank=0, world=1, driver=None, **kw):

@@ -271,7 +271,7 @@ class Engine:
             out.update(FA=F4[:, 0], FB=F4[:, 1], FcAB=F4[:, 2], FAB=F4[:, 3])
         return out
 
-    TERM_IDS = {"Ed-Epf": 0, "1-MCC": 1, "sln_Epf": 2, "Ed-MFE": 3, "1-precision": 4, "1-recall": 5}
+    TERM_IDS = {"Ed-Epf": 0, "1-MCC": 1, "sln_Epf": 2, "Ed-MFE": 3, "1-precision": 4, "1-recall": 5, "Edef": 6}
 
     def mc_run(self, prob, n_iter, shelf_index, n_shelves, tm_max, tm_min, targeted, temps, scoring_f, flags, rng_state, state,
                counters, best, L_const=504.12):

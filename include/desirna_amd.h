@@ -269,7 +269,7 @@ int drna_metropolis_batch(int R, const double *score_o, const double *score_m, c
  * single_replica_design (utils/replica_exchange_monte_carlo.py:176-210) for R replicas in lock-step: proposal
  * (drna_propose_batch[_alt] rules; partner / snake arrays may be NULL / 0 for plain targets), scoring of the R proposals on the
  * GPU (drna_score_batch with flags | PF | MFE | EVAL against the structures of drna_set_targets), SimScore, the -sf sum
- * (term_id: 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall; weights term_w; + mean E(alt) - Epf when
+ * (term_id: 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall, 6 Edef; weights term_w; + mean E(alt) - Epf when
  * alternative structures are installed), Metropolis acceptance, state update.
  *   in/out per replica: seqs, mfe_ss (R*L chars), score, mcc1 (= 1 - MCC), Epf, Ed (kcal/mol), rng_state
  *   counters[3] += accepted, accepted-better, rejected;  best[4] = {1-MCC, score, Epf, Ed} and best_seq / best_ss (L chars)

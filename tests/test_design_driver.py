@@ -380,6 +380,23 @@ def test_native_mc_loop_equals_python_loop_on_gpu(eterna_targets):
 
 
 @pytest.mark.gpu
+def test_native_mc_loop_with_ensemble_defect_term(eterna_targets):
+    """-sf with an Edef term (reference utils/energy_scores.py:362-374,397-398) stays on the native loop (term 6 of drna_mc_run:
+    inside + outside recursion of every proposal) and walks the same trajectory as the per-iteration Python loop."""
+    tg = "((((((.((((((((....))))).)).).))))))"
+    inp = SimpleNamespace(name="edef", sec_struct=tg, seq_restr="N" * len(tg), seed_seq=None, alt_sec_struct=None,
+                          alt_sec_structs=None)
+    sf = "Ed-Epf:0.5,Edef:1.0"
+    a = design.run_design_fast(inp, replicas=8, exchange=10, steps=3, seed=5, native_loop=True, scoring_f=sf)
+    b = design.run_design_fast(inp, replicas=8, exchange=10, steps=3, seed=5, native_loop=False, scoring_f=sf)
+    assert a["used_native_loop"] and not b["used_native_loop"]
+    assert [r["sequence"] for r in a["simulation_data"]] == [r["sequence"] for r in b["simulation_data"]]
+    assert [r["scoring_function"] for r in a["simulation_data"]] == [r["scoring_function"] for r in b["simulation_data"]]
+    for k in ("acc_mc", "acc_mc_better", "rej_mc", "acc_re", "rej_re", "scored"):
+        assert a["stats"][k] == b["stats"][k], k
+
+
+@pytest.mark.gpu
 def test_avoid_oligomerization_design_run_builds_its_own_engines():
     """-oa on through run_design WITHOUT an injected engine: every candidate is also folded against itself (s & s, 2 L
     nucleotides), which needs an engine sized for 2 L (reference utils/energy_scores.py:411-418)."""

@@ -745,7 +745,37 @@ def test_flag_epochs_are_reset_before_the_compare_range_runs_out(eng400, oracle)
         a, b = eng400.score_batch(long_seqs, flags), eng400.score_batch(short, flags)
         assert a["mfe_ss"] == ref_l["mfe_ss"] and (a["Epf"].view(np.int64) == ref_l["Epf"].view(np.int64)).all()
         assert b["mfe_ss"] == ref_s["mfe_ss"] and (b["Epf"].view(np.int64) == ref_s["Epf"].view(np.int64)).all()
-    assert eng400.get_option("flag_resets") == r0 + 2          # strips and two-workgroup flags, once each
+    assert eng400.get_option("flag_resets") == r0 + 3          # strips, two-workgroup MFE and partition-function helper flags, once each
     assert eng400.get_option("debug_epoch") < 64 and eng400.get_option("sync_fallbacks") == f0
     ss, e = oracle.mfe(short[0])
     assert ref_s["mfe_ss"][0] == ss and int(ref_s["Emfe"][0]) == e
+
+
+def test_lost_pf_helper_costs_milliseconds(eng400, oracle):
+    """The helper workgroup of the partition function may never show up (HIP promises no dispatch order).  Its waits are bounded
+    by TIME (10 ms of the wall clock, not a poll count worth seconds): injected here -- the helpers leave at once -- the call
+    comes back within tens of milliseconds, redone without helpers, with the same bits, and is counted."""
+    import time
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(31337)
+    L = 200
+    seqs = [_rand(rng, L) for _ in range(8)]
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL
+    eng400.set_targets(["." * L])
+    ref = eng400.score_batch(seqs, flags)
+    assert eng400.get_option("last_workgroups") == 4 * len(seqs)          # two workgroups per fold for both folds
+    before = eng400.get_option("sync_fallbacks")
+    try:
+        eng400.set_option("helper_fault", 1)
+        t0 = time.perf_counter()
+        a = eng400.score_batch(seqs, flags)
+        dt = time.perf_counter() - t0
+    finally:
+        eng400.set_option("helper_fault", 0)
+    assert eng400.get_option("sync_fallbacks") == before + 1
+    INJECTED_FALLBACKS.append(1)
+    assert dt < 0.05, dt
+    assert a["mfe_ss"] == ref["mfe_ss"] and (a["Epf"].view(np.int64) == ref["Epf"].view(np.int64)).all() and (a["Ed"] == ref["Ed"]).all()
+    b = eng400.score_batch(seqs, flags)                                      # and the next call uses the helpers again
+    assert eng400.get_option("sync_fallbacks") == before + 1 and (b["Epf"].view(np.int64) == ref["Epf"].view(np.int64)).all()
+    assert abs(float(ref["Epf"][0]) - oracle.pf(seqs[0])) < EPF_TOL_ORACLE
