@@ -183,6 +183,10 @@ def roofline_block(dom, dom_ms, L, R, tk):
         a = k["lds_busy_cycles_per_cu"] / t
         bounds["lds"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G LDS-array cycles/s per CU", "frac": a / clk,
                          "bank_conflict_share": k.get("lds_bank_conflict_share")}
+        if k.get("workgroups") and k["workgroups"] > R:
+            # kernels with a helper workgroup per fold: the counters are sums over main and helper CUs; if ALL of the LDS
+            # traffic were the main workgroups' (the helpers' is small), their CUs would be this busy
+            bounds["lds"]["frac_main_cus_upper"] = a / clk * k["workgroups"] / R
     if k.get("valu_busy_cycles_per_simd"):
         # the inputs file prices an instruction at 4 cycles (valu_cycles_per_count); the pipe itself takes 2
         insts = k["valu_busy_cycles_per_simd"] / inp.get("valu_cycles_per_count", 4.0)
@@ -199,8 +203,8 @@ def roofline_block(dom, dom_ms, L, R, tk):
                     "inputs": "profiles/roofline_inputs.json (%s)" % inp.get("source", "?")})
     if k.get("floor_ms"):
         out["own_floor"] = {"floor_ms": k["floor_ms"], "frac": k["floor_ms"] / dom_ms,
-                            "note": "same kernel, every sweep phase left out (finalize + barrier only): this implementation's "
-                                    "dependency chain, not a hardware peak"}
+                            "note": "one-workgroup-per-fold build of the same source with every sweep phase left out (finalize + "
+                                    "barrier only): this implementation's dependency chain, not a hardware peak"}
     out["workgroups"] = k.get("workgroups")
     return out
 
@@ -301,6 +305,11 @@ def main():
         from desirna_amd.workloads import design_like_sequences
         seqs = design_like_sequences(target, R, rng)
     eng = E.Engine(max_R=R, max_L=L, device=local_rank)
+    if backend == "gloo" and world > max(1, torch.cuda.device_count()):
+        # rehearsal with several ranks on ONE card: the folds by several workgroups assume the whole chip (every workgroup of a
+        # launch resident at once), which ranks sharing a card do not have
+        eng.set_option("pf_helper", 0)
+        eng.set_option("dual", 0)
     eng.set_targets([target])
     flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL
 

@@ -242,6 +242,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   e->cus = prop.multiProcessorCount;
   if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
+  if (const char* hv = getenv("DRNA_PF_HELPER")) e->pf_helper = atoi(hv) != 0;
   if (const char* sv = getenv("DRNA_STRIPS")) { const int v = atoi(sv); e->strips = v < 0 ? 0 : v > 2 ? 2 : v; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));

@@ -22,6 +22,18 @@ def key_of(kname):
     return None
 
 
+def grid_workgroups():
+    """workgroups per launch of every kernel, from the kernel trace of a PMC pass"""
+    out = {}
+    for f in glob.glob(os.path.join(G, "pmc_sq1", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            try:
+                out[r["Kernel_Name"]] = float(r["Grid_Size_X"]) / float(r["Workgroup_Size_X"])
+            except Exception:
+                pass
+    return out
+
+
 raw, cal = {}, {}
 for p in ("fetch", "write", "sq1", "sq2", "grbm"):
     for k, d in counters("pmc", p).items():
@@ -64,14 +76,15 @@ except Exception:
 # the measured counter value per such instruction converts SQ_LDS_IDX_ACTIVE to LDS-array cycles
 lds_unit = 2.0 / units["SQ_LDS_IDX_ACTIVE_per_ds_read_b64"] if units.get("SQ_LDS_IDX_ACTIVE_per_ds_read_b64") else 1.0
 valu_unit = 4.0 / units["SQ_ACTIVE_INST_VALU_per_v_add"] if units.get("SQ_ACTIVE_INST_VALU_per_v_add") else 4.0
-out = {"source": "tools/gpu_round2.sh pmc+floor passes at %s; per-launch averages, R=64 x L=200 uniform batch" % head,
+out = {"source": "tools/gpu_round3.sh pmc+floor passes at %s; per-launch averages, R=64 x L=200 uniform batch" % head,
        "units": units, "lds_cycles_per_count": lds_unit, "valu_cycles_per_count": valu_unit, "raw": {}, "kernels": {}}
+GW = grid_workgroups()
 for k, d in raw.items():
     key = key_of(k)
     if key is None:
         continue
     out["raw"][k] = d
-    wgs = 128.0 if "dual" in k else 64.0         # one workgroup = one CU per sequence; two per sequence in the two-workgroup kernel
+    wgs = GW.get(k, 128.0 if "dual" in k else 64.0)      # one workgroup = one CU; two per sequence in the kernels with a helper
     e = {}
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         # MI355X_MICROARCH.md (HBM): both counters are KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2
