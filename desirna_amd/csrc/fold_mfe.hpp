@@ -386,14 +386,66 @@ struct FmlGlobal {
   __device__ __forceinline__ int operator()(int d, int i) const { return p[d * ld + i]; }
 };
 
-template <class SM, class FMLACC>
-__device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
-                                     const FMLACC FML, const int32_t* __restrict__ EXT) {
+// Sector containers of the traceback.  TbStack: the private stack of the one-wave traceback (general and strip kernels).  TbShared
+// (round 3, LDS-resident kernels): a queue in LDS that several waves work from -- the sectors of a structure (exterior stems, the
+// branches of a multiloop) are independent, the traceback is ~0.9 us of mostly scalar control flow per event, and one wave took
+// 0.074 of the MFE fold's 0.50 ms at 200 nt with fifteen waves idle.  Entry c is published by its ml + 1 in sec_ml[c] (0 = not
+// written yet); tbq = {next to claim, next free, sectors pushed and not finished, 1 done / 2 failed}.  The caller zeroes sec_ml
+// and tbq and writes entry 0 before the barrier in front of the traceback.
+template <class SM> struct TbStack {
+  SM& sm;
+  int sp = 0;
+  __device__ __forceinline__ void init(int n) { sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 0; sp = 1; }
+  __device__ __forceinline__ bool pop(int& i, int& j, int& ml) {
+    if (sp == 0) return false;
+    sp--;
+    i = sm.sec_i[sp]; j = sm.sec_j[sp]; ml = sm.sec_ml[sp];
+    return true;
+  }
+  __device__ __forceinline__ void push(int i, int j, int ml) { sm.sec_i[sp] = (short)i; sm.sec_j[sp] = (short)j; sm.sec_ml[sp] = (unsigned char)ml; sp++; }
+  __device__ __forceinline__ void done_one() {}
+  __device__ __forceinline__ void fail() {}
+  __device__ __forceinline__ bool failed() const { return false; }
+};
+template <class SM> struct TbShared {
+  SM& sm;
+  __device__ __forceinline__ void init(int) {}
+  __device__ __forceinline__ bool pop(int& i, int& j, int& ml) {
+    int c = 0;
+    if (lane_id() == 0) c = atomicAdd(&sm.tbq[0], 1);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (c > (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])) - 1) return false;
+    for (;;) {
+      const int m = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned char*>(&sm.sec_ml[c]));
+      if (m) { i = sm.sec_i[c]; j = sm.sec_j[c]; ml = m - 1; return true; }
+      if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&sm.tbq[3]))) return false;
+      spin_pause();
+    }
+  }
+  __device__ __forceinline__ void push(int i, int j, int ml) {
+    if (lane_id() == 0) {
+      atomicAdd(&sm.tbq[2], 1);
+      const int c = atomicAdd(&sm.tbq[1], 1);
+      if (c > (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])) - 1) { *reinterpret_cast<volatile int*>(&sm.tbq[3]) = 2; return; }   // (cannot happen for n <= NLEN)
+      sm.sec_i[c] = (short)i; sm.sec_j[c] = (short)j;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      *reinterpret_cast<volatile unsigned char*>(&sm.sec_ml[c]) = (unsigned char)(ml + 1);
+    }
+  }
+  __device__ __forceinline__ void done_one() {
+    if (lane_id() == 0 && atomicAdd(&sm.tbq[2], -1) == 1) *reinterpret_cast<volatile int*>(&sm.tbq[3]) = 1;
+  }
+  __device__ __forceinline__ void fail() { if (lane_id() == 0) *reinterpret_cast<volatile int*>(&sm.tbq[3]) = 2; }
+  __device__ __forceinline__ bool failed() const { return *reinterpret_cast<volatile int*>(&sm.tbq[3]) == 2; }
+};
+
+template <class SM, class FMLACC, class QUEUE>
+__device__ inline bool mfe_traceback_q(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
+                                       const FMLACC FML, const int32_t* __restrict__ EXT, QUEUE Q) {
   const MfeTables& T = *A.T;
   const Plan& P = *A.plan;
   const int n = A.L, ld = A.ld, lane = lane_id();
   const int HALF = INF_DEV / 2;
-  int sp = 0;
   bool ok = true;
   // The interior scan gives lane l of round r the candidate k = 64 r + l of the canonical order.  Its shape, its kind and its
   // size term (what E_IntLoop adds for the loop size and asymmetry) are fixed for the whole traceback: fetched and computed
@@ -418,16 +470,13 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
     tb_shape[rnd] = u1 | (u2 << 8) | (kind << 16);
     tb_L[rnd] = L;
   }
-  // sector stack lives in LDS; every lane keeps the same sp
-  sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 0; sp = 1;
-  while (sp > 0 && ok) {
-    sp--;
-    int i = sm.sec_i[sp], j = sm.sec_j[sp];
-    const int ml = sm.sec_ml[sp];
+  // one sector: an exterior interval (ml 0), a multiloop segment (ml 1); returns false when a table value cannot be reproduced
+  Q.init(n);
+  auto sector = [&](int i, int j, const int ml) -> bool {
     bool have_pair = false;
     if (ml == 0) {
       // ---- exterior: vrna_BT_ext_loop_f5
-      if (j < TURN + 2) continue;
+      if (j < TURN + 2) return true;
       // largest jj <= j with f5[jj] != f5[jj-1]
       int jj = -1;
       for (int base = j; base >= 1 && jj < 0; base -= WAVE) {
@@ -436,7 +485,7 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
         const int fl = first_lane(__ballot(hit));
         if (fl >= 0) jj = base - fl;
       }
-      if (jj < TURN + 2) continue;
+      if (jj < TURN + 2) return true;
       const int fij = sm.f5[jj];
       int u = -1;
       for (int base = jj - TURN - 1; base >= 1 && u < 0; base -= WAVE) {
@@ -449,8 +498,8 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
         const int fl = first_lane(__ballot(hit));
         if (fl >= 0) u = base - fl;
       }
-      if (u < 0) { ok = false; break; }
-      sm.sec_i[sp] = 1; sm.sec_j[sp] = (short)(u - 1); sm.sec_ml[sp] = 0; sp++;
+      if (u < 0) return false;
+      Q.push(1, (u - 1), 0);
       i = u; j = jj; have_pair = true;
     } else if (ml == 1) {
       // ---- multiloop segment: vrna_BT_mb_loop_split
@@ -477,7 +526,7 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
         if (fl >= 0) { i += fl; break; }
         i += WAVE;
       }
-      if (j < i + TURN + 1) { ok = false; break; }
+      if (j < i + TURN + 1) return false;
       const int d = j - i;
       const int fij = FML(d, i);
       const int w = Wc[d * ld + i];
@@ -495,9 +544,9 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
           const int fl = first_lane(__ballot(hit));
           if (fl >= 0) u = base + fl;
         }
-        if (u < 0) { ok = false; break; }
-        sm.sec_i[sp] = (short)i; sm.sec_j[sp] = (short)u; sm.sec_ml[sp] = 1; sp++;
-        sm.sec_i[sp] = (short)(u + 1); sm.sec_j[sp] = (short)j; sm.sec_ml[sp] = 1; sp++;
+        if (u < 0) return false;
+        Q.push(i, u, 1);
+        Q.push((u + 1), j, 1);
       }
     } else {
       have_pair = true;
@@ -558,14 +607,28 @@ __device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __
         const int fl = first_lane(__ballot(hit));
         if (fl >= 0) u = base + fl;
       }
-      if (u < 0) { ok = false; break; }
-      sm.sec_i[sp] = (short)(i + 1); sm.sec_j[sp] = (short)u; sm.sec_ml[sp] = 1; sp++;
-      sm.sec_i[sp] = (short)(u + 1); sm.sec_j[sp] = (short)(j - 1); sm.sec_ml[sp] = 1; sp++;
+      if (u < 0) return false;
+      Q.push((i + 1), u, 1);
+      Q.push((u + 1), (j - 1), 1);
       break;
     }
+    return true;
+  };
+  int qi = 0, qj = 0, qml = 0;
+  while (Q.pop(qi, qj, qml)) {
+    if (!sector(qi, qj, qml)) { Q.fail(); ok = false; break; }
+    Q.done_one();
   }
-  return ok;
+  return ok && !Q.failed();
 }
+
+// the one-wave traceback with a private stack
+template <class SM, class FMLACC>
+__device__ inline bool mfe_traceback(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
+                                     const FMLACC FML, const int32_t* __restrict__ EXT) {
+  return mfe_traceback_q(sm, A, Wc, FML, EXT, TbStack<SM>{sm});
+}
+
 
 // ---- the kernel: one workgroup per sequence
 

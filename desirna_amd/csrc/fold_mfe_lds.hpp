@@ -52,6 +52,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int eshape[128];               // bulge / 1xn shapes of the shape-uniform E items: s = u1+u2 | u1 << 8 | size term << 16 (static)
   int eshape_rows[128];          // shape slots of the 16-lane-row E items (one-workgroup kernel): s | kind << 5 | u1 << 8 | size term << 16
   int sync_fail;                 // two-workgroup kernel: a wait for the helper expired
+  int tbq[4];                    // sector queue of the traceback (TbShared, fold_mfe.hpp)
   int etab[2][128];              // the same shapes as seen from one diagonal: byte offset of the inner pair's ring cell
                                  // for column 0 | size term << 16 (shapes without an inner pair yet point at the INF row)
   int tw_L[32];                  // generic interior size term by total loop size s (INF below 6)
@@ -905,16 +906,24 @@ __device__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int r, DualLink lk)
     const long long pc1 = wall_clock64();
 #endif
     if (DUAL && sm.sync_fail) { status = ST_SYNC; break; }
-    if (wave_id() == 0) {
-      const bool ok = (DRNA_SKIP & 256) ? true : mfe_traceback(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT);
+    // traceback by TB_WAVES waves working from one queue of sectors in LDS (TbShared): entry 0 = the whole exterior interval
+    constexpr int TB_WAVES = NT / WAVE < 8 ? NT / WAVE : 8;
+    for (int k = tid; k < (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])); k += NT) sm.sec_ml[k] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 1;          // ml 0, published
+      sm.tbq[0] = 0; sm.tbq[1] = 1; sm.tbq[2] = 1; sm.tbq[3] = 0;
+    }
+    __syncthreads();
+    if (!(DRNA_SKIP & 256) && wave_id() < TB_WAVES) (void)mfe_traceback_q(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT, TbShared<MfeFastSmem<NT>>{sm});
+    __syncthreads();
 #ifdef DRNA_PHASECLK
-      if (blockIdx.x == 0 && lane_id() == 0)
-        printf("mfe_lds_kernel: fill %lld traceback %lld (100 MHz ticks)\n", pc1 - pc0, wall_clock64() - pc1);
+    if (blockIdx.x == 0 && tid == 0)
+      printf("mfe_lds_kernel: fill %lld traceback %lld (100 MHz ticks)\n", pc1 - pc0, wall_clock64() - pc1);
 #endif
-      if (lane_id() == 0) {
-        if (round == 0) A.Emfe[r] = sm.f5[n];
-        sm.flag = ok ? 0 : 1;
-      }
+    if (tid == 0) {
+      if (round == 0) A.Emfe[r] = sm.f5[n];
+      sm.flag = (!(DRNA_SKIP & 256) && sm.tbq[3] == 2) ? 1 : 0;
     }
     __syncthreads();
     PCLK(6);
