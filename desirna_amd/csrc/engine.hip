@@ -45,6 +45,8 @@ struct drna_engine {
   int32_t* d_ws_mfe = nullptr;
   double* d_ws_pf = nullptr;
   size_t ws_bytes = 0;
+  int ws_slots = 0;               // sequences the fold workspaces hold at once: max_R, or fewer under the workspace budget (DRNA_WS_GB,
+                                  // default 8): larger batches are folded in chunks of ws_slots, back to back on the same streams
   // staging for the host-buffer entry point
   char* d_seqs = nullptr;
   double* d_Epf = nullptr;
@@ -254,7 +256,16 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(upload(&e->d_scale, e->H.scale.data(), e->H.scale.size()));
   HIP_TRY(upload(&e->d_eMLb, e->H.eMLb.data(), e->H.eMLb.size()));
   const int ld = max_L + 2;
-  size_t bm = mfe_ws_stride(ld) * sizeof(int32_t) * max_R, bp = pf_ws_stride(ld) * sizeof(double) * max_R;
+  {
+    // O(ld^2) tables per sequence: 7 fp64 + 5 int32 tables, 12.3 MB at 400 nt.  A batch of 3,200 sequences used to take 39.8 GB;
+    // the workspaces now hold at most DRNA_WS_GB (default 8) and a larger batch goes through them in chunks
+    double gb = 8.0;
+    if (const char* g = getenv("DRNA_WS_GB")) gb = std::max(0.05, atof(g));
+    const double per = (double)mfe_ws_stride(ld) * sizeof(int32_t) + (double)pf_ws_stride(ld) * sizeof(double);
+    const long long fit = (long long)(gb * 1e9 / per);
+    e->ws_slots = (int)std::max(1ll, std::min((long long)max_R, fit));
+  }
+  size_t bm = mfe_ws_stride(ld) * sizeof(int32_t) * e->ws_slots, bp = pf_ws_stride(ld) * sizeof(double) * e->ws_slots;
   HIP_TRY(hipMalloc((void**)&e->d_ws_mfe, bm));
   HIP_TRY(hipMalloc((void**)&e->d_ws_pf, bp));
   e->ws_bytes = bm + bp;
@@ -352,6 +363,7 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!strcmp(name, "pf_helper")) { *value = e->pf_helper ? 1 : 0; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
   if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
+  if (!strcmp(name, "workspace_slots")) { *value = e->ws_slots; return DRNA_OK; }
   if (!strcmp(name, "flag_resets")) { *value = e->flag_resets; return DRNA_OK; }
   if (!strcmp(name, "debug_epoch")) { *value = std::max(e->pfh_epoch, std::max(e->strip_epoch, e->dual_epoch)); return DRNA_OK; }
   return DRNA_ERR_ARG;
@@ -416,6 +428,18 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     return DRNA_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(e->device));
+  if (R > e->ws_slots) {
+    // more sequences than the workspaces hold (DRNA_WS_GB): one sub-batch of ws_slots after the other
+    const int nt = std::max(1, e->n_targets);
+    for (int r0 = 0; r0 < R; r0 += e->ws_slots) {
+      const int m = std::min(e->ws_slots, R - r0);
+      const int rc = drna_score_batch_device(e, m, L, d_seqs + (size_t)r0 * L, flags, d_Epf ? d_Epf + r0 : nullptr,
+                                             d_Emfe ? d_Emfe + r0 : nullptr, d_mfe_ss ? d_mfe_ss + (size_t)r0 * L : nullptr,
+                                             d_Ed ? d_Ed + (size_t)r0 * nt : nullptr);
+      if (rc != DRNA_OK) return rc;
+    }
+    return DRNA_OK;
+  }
   const int ld = L + 2;
   for (int k = 0; k < 2 * e->max_R; k++) e->h_status[k] = ST_OK;
   // small batches leave most CUs idle with one workgroup per fold (R = 64: 128 workgroups on 256 CUs): the MFE fold then
@@ -718,6 +742,7 @@ extern "C" int drna_ensemble_defect_batch_device(drna_engine* e, int R, int L, c
     e->err = "drna_ensemble_defect_batch: needs drna_set_targets() with the same L (targets[0] is the reference structure)";
     return DRNA_ERR_ARG;
   }
+  if (R > e->ws_slots) { e->err = "drna_ensemble_defect_batch: batch larger than the workspace (raise DRNA_WS_GB or split the batch)"; return DRNA_ERR_ARG; }
   HIP_TRY(hipSetDevice(e->device));
   const int ldmax = e->max_L + 2, ld = L + 2;
   if (!e->d_ws_out) {
@@ -849,15 +874,17 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     e->err = "drna_score_ragged: bad argument (R within the engine's limit; output pointers for every requested flag)";
     return DRNA_ERR_ARG;
   }
-  // descriptors: len | off | target_of | index list of the LDS-resident kernels | of the general kernels | partition
-  // function only: of the strip kernels (longest first, i.e. by falling number of strips) | of the general kernel
-  std::vector<int> h((size_t)7 * R);
-  int* off = h.data() + R;
+  // The batch is folded in SORTED order, longest first: position q on the device is sequence order[q] of the caller.  Then
+  // (a) the three classes -- strips (n > 200), general kernels, LDS-resident kernels (n <= 200) -- are ranges of q, and (b) a
+  // batch larger than the workspaces (ws_slots sequences, DRNA_WS_GB) goes through them in CHUNKS of consecutive q: chunk c
+  // uses slot q - c0, i.e. a workspace pointer moved back by c0 slots, its launches queue behind the previous chunk's on the
+  // same streams (the MFE stream owns the MFE workspace, the partition-function stream the other), and nothing waits in between.
+  // descriptors: len | off | target_of | index lists (q values) of the LDS-resident kernels | - | strip kernels | general kernels
+  std::vector<int> order(R);
+  std::iota(order.begin(), order.end(), 0);
   size_t total = 0;
   for (int r = 0; r < R; r++) {
     if (lens[r] < 1 || lens[r] > e->max_L) { e->err = "drna_score_ragged: sequence length outside [1, max_L]"; return DRNA_ERR_ARG; }
-    h[r] = lens[r];
-    off[r] = (int)total;
     total += (size_t)lens[r];
     if (want_ev) {
       const int t = target_of[r];
@@ -865,31 +892,40 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
         e->err = "drna_score_ragged: target_of[r] must name a structure of drna_set_targets_ragged() with the sequence's length";
         return DRNA_ERR_ARG;
       }
-      h[(size_t)2 * R + r] = t;
     }
   }
   if (total > (size_t)e->max_R * e->max_L) { e->err = "drna_score_ragged: more nucleotides than max_R * max_L"; return DRNA_ERR_ARG; }
-  std::vector<int> order(R);
-  std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });   // longest first
-  const bool fast_ok = e->lds_path && e->nt == 1024;
-  int nA = 0, nB = 0;
-  int *idxA = h.data() + (size_t)3 * R, *idxB = h.data() + (size_t)4 * R;
-  int nC = 0, nD = 0;
-  int *idxC = h.data() + (size_t)5 * R, *idxD = h.data() + (size_t)6 * R;
-  const int ld = e->max_L + 2;
-  for (int r : order) {
-    if (fast_ok && lens[r] <= MFE_FAST_NMAX && lens[r] <= PF_FAST_NMAX) idxA[nA++] = r;
-    else {
-      idxB[nB++] = r;
-      if (strips_for(e, lens[r], ld) && lens[r] > PF_FAST_NMAX) idxC[nC++] = r;
-      else idxD[nD++] = r;
+  std::vector<size_t> src_off(R);
+  { size_t o = 0; for (int r = 0; r < R; r++) { src_off[r] = o; o += (size_t)lens[r]; } }
+  std::vector<int> h((size_t)7 * R);
+  std::vector<char> sorted_seqs(total);
+  int* off = h.data() + R;
+  {
+    size_t o = 0;
+    for (int q = 0; q < R; q++) {
+      const int r = order[q];
+      h[q] = lens[r];
+      off[q] = (int)o;
+      memcpy(sorted_seqs.data() + o, seqs + src_off[r], (size_t)lens[r]);
+      o += (size_t)lens[r];
+      if (want_ev) h[(size_t)2 * R + q] = target_of[r];
     }
+  }
+  const bool fast_ok = e->lds_path && e->nt == 1024;
+  int nA = 0, nC = 0, nD = 0;
+  int *idxA = h.data() + (size_t)3 * R, *idxC = h.data() + (size_t)5 * R, *idxD = h.data() + (size_t)6 * R;
+  const int ld = e->max_L + 2;
+  for (int q = 0; q < R; q++) {
+    const int len = h[q];
+    if (fast_ok && len <= MFE_FAST_NMAX && len <= PF_FAST_NMAX) idxA[nA++] = q;
+    else if (strips_for(e, len, ld) && len > PF_FAST_NMAX) idxC[nC++] = q;
+    else idxD[nD++] = q;
   }
   HIP_TRY(hipSetDevice(e->device));
   if (!e->d_rg) HIP_TRY(hipMalloc((void**)&e->d_rg, (size_t)7 * e->max_R * sizeof(int)));
   HIP_TRY(hipMemcpy(e->d_rg, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->d_seqs, seqs, total, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_seqs, sorted_seqs.data(), total, hipMemcpyHostToDevice));
   if (want_ev && R > 0) {
     if (!e->d_Ed) HIP_TRY(hipMalloc((void**)&e->d_Ed, (size_t)e->max_R * std::max(1, e->n_targets) * sizeof(int32_t)));
   }
@@ -897,7 +933,12 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
   if ((want_pf || want_mfe) && nC) { const int rc = strip_flags(e, want_mfe); if (rc != DRNA_OK) return rc; }
   Ragged rg;
   rg.len = e->d_rg; rg.off = e->d_rg + R;
-  const int* d_idxA = e->d_rg + (size_t)3 * R;
+  // the part of an index list (ascending q) that falls into the chunk [c0, c1)
+  auto part = [&](const int* idx, int cnt, int c0, int c1, int& first, int& num) {
+    first = (int)(std::lower_bound(idx, idx + cnt, c0) - idx);
+    num = (int)(std::lower_bound(idx, idx + cnt, c1) - idx) - first;
+  };
+  const int slots = e->ws_slots;
   HIP_TRY(hipEventRecord(e->ev_start, e->s_mfe));
   HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_start, 0));
   HIP_TRY(hipStreamWaitEvent(e->s_eval, e->ev_start, 0));
@@ -905,27 +946,35 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     MfeArgs a;
     a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = e->d_seqs; a.L = 0; a.ld = ld;
     a.pk_rounds = want_pk ? 3 : 0;
-    a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
+    a.ws_stride = (long long)mfe_ws_stride(ld);
     a.Emfe = e->d_Emfe; a.ss = e->d_ss; a.status = e->d_status;
     a.rg = rg;
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
-    a.rg.idx = nullptr;
-    for (int k = 0; k < nC;) {                      // the long sequences first: strip kernels, one launch per number of strips
-      const int S = strips_for(e, lens[idxC[k]], ld);
-      int m = k;
-      while (m < nC && strips_for(e, lens[idxC[m]], ld) == S) m++;
-      launch_mfe_strips(e, a, m - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_mfe);
-      k = m;
-    }
-    if (nD) {
-      a.rg.idx = e->d_rg + (size_t)6 * R;
-      if (e->nt == 256) launch_mfe<256>(a, nD, e->s_mfe);
-      else if (e->nt == 512) launch_mfe<512>(a, nD, e->s_mfe);
-      else launch_mfe<1024>(a, nD, e->s_mfe);
-    }
-    if (nA) {
-      a.rg.idx = d_idxA;
-      hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_mfe, a);
+    for (int c0 = 0; c0 < R; c0 += slots) {
+      const int c1 = std::min(R, c0 + slots);
+      a.ws = e->d_ws_mfe - (long long)c0 * a.ws_stride;           // slot of sequence q: q - c0
+      int f, m;
+      part(idxC, nC, c0, c1, f, m);
+      a.rg.idx = nullptr;
+      for (int k = f; k < f + m;) {                 // the long sequences first: strip kernels, one launch per number of strips
+        const int S = strips_for(e, h[idxC[k]], ld);
+        int k2 = k;
+        while (k2 < f + m && strips_for(e, h[idxC[k2]], ld) == S) k2++;
+        launch_mfe_strips(e, a, k2 - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_mfe);
+        k = k2;
+      }
+      part(idxD, nD, c0, c1, f, m);
+      if (m) {
+        a.rg.idx = e->d_rg + (size_t)6 * R + f;
+        if (e->nt == 256) launch_mfe<256>(a, m, e->s_mfe);
+        else if (e->nt == 512) launch_mfe<512>(a, m, e->s_mfe);
+        else launch_mfe<1024>(a, m, e->s_mfe);
+      }
+      part(idxA, nA, c0, c1, f, m);
+      if (m) {
+        a.rg.idx = e->d_rg + (size_t)3 * R + f;
+        hipLaunchKernelGGL(mfe_lds_kernel<1024>, dim3(m), dim3(1024), 0, e->s_mfe, a);
+      }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
@@ -934,27 +983,35 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     PfArgs a;
     a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
     a.seqs = e->d_seqs; a.L = 0; a.ld = ld;
-    a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
+    a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = e->d_Epf; a.status = e->d_status + e->max_R;
     a.rg = rg;
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
-    a.rg.idx = nullptr;
-    for (int k = 0; k < nC;) {                      // the strip kernel: one launch per number of strips, most strips first
-      const int S = strips_for(e, lens[idxC[k]], ld);
-      int m = k;
-      while (m < nC && strips_for(e, lens[idxC[m]], ld) == S) m++;
-      launch_pf_strips(e, a, m - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_pf);
-      k = m;
-    }
-    if (nD) {
-      a.rg.idx = e->d_rg + (size_t)6 * R;
-      if (e->nt == 256) launch_pf<256>(a, nD, e->s_pf);
-      else if (e->nt == 512) launch_pf<512>(a, nD, e->s_pf);
-      else launch_pf<1024>(a, nD, e->s_pf);
-    }
-    if (nA) {
-      a.rg.idx = d_idxA;
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(nA), dim3(1024), 0, e->s_pf, a, EvalArgs{});
+    for (int c0 = 0; c0 < R; c0 += slots) {
+      const int c1 = std::min(R, c0 + slots);
+      a.ws = e->d_ws_pf - (long long)c0 * a.ws_stride;
+      int f, m;
+      part(idxC, nC, c0, c1, f, m);
+      a.rg.idx = nullptr;
+      for (int k = f; k < f + m;) {                 // the strip kernel: one launch per number of strips, most strips first
+        const int S = strips_for(e, h[idxC[k]], ld);
+        int k2 = k;
+        while (k2 < f + m && strips_for(e, h[idxC[k2]], ld) == S) k2++;
+        launch_pf_strips(e, a, k2 - k, S, k, e->d_rg + (size_t)5 * R + k, e->s_pf);
+        k = k2;
+      }
+      part(idxD, nD, c0, c1, f, m);
+      if (m) {
+        a.rg.idx = e->d_rg + (size_t)6 * R + f;
+        if (e->nt == 256) launch_pf<256>(a, m, e->s_pf);
+        else if (e->nt == 512) launch_pf<512>(a, m, e->s_pf);
+        else launch_pf<1024>(a, m, e->s_pf);
+      }
+      part(idxA, nA, c0, c1, f, m);
+      if (m) {
+        a.rg.idx = e->d_rg + (size_t)3 * R + f;
+        hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(m), dim3(1024), 0, e->s_pf, a, EvalArgs{});
+      }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
@@ -978,8 +1035,8 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
   if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
   if (want_ev) HIP_TRY(hipEventElapsedTime(&e->timing[2], e->ev_e0, e->ev_e1));
   HIP_TRY(hipEventElapsedTime(&e->timing[3], e->ev_start, e->ev_end));
-  for (int r = 0; r < R; r++) {
-    const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
+  for (int q = 0; q < R; q++) {
+    const int sm = want_mfe ? e->h_status[q] : ST_OK, sp = want_pf ? e->h_status[e->max_R + q] : ST_OK;
     const int st = sm != ST_OK ? sm : sp;
     if (st == ST_OK) continue;
     if (st == ST_SYNC && !e->in_fallback) {               // (see drna_score_batch_device)
@@ -994,16 +1051,28 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     snprintf(buf, sizeof buf, st == ST_BAD_CHAR ? "sequence %d holds a character other than A C G U T"
                               : st == ST_PF_RANGE ? "sequence %d: partition function left the fp64 range"
                               : st == ST_SYNC ? "sequence %d: the two workgroups of the fold lost each other (wait expired)"
-                                                  : "sequence %d: traceback could not reproduce a table value", r);
+                                                  : "sequence %d: traceback could not reproduce a table value", order[q]);
     e->err = buf;
     return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;
   }
-  if (want_pf) HIP_TRY(hipMemcpy(Epf, e->d_Epf, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
-  if (want_mfe) {
-    HIP_TRY(hipMemcpy(Emfe, e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(mfe_ss, e->d_ss, total, hipMemcpyDeviceToHost));
+  // results back in the caller's order
+  if (want_pf) {
+    std::vector<double> t(R);
+    HIP_TRY(hipMemcpy(t.data(), e->d_Epf, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
+    for (int q = 0; q < R; q++) Epf[order[q]] = t[q];
   }
-  if (want_ev) HIP_TRY(hipMemcpy(Ed, e->d_Ed, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (want_mfe) {
+    std::vector<int32_t> t(R);
+    HIP_TRY(hipMemcpy(t.data(), e->d_Emfe, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int q = 0; q < R; q++) Emfe[order[q]] = t[q];
+    HIP_TRY(hipMemcpy(sorted_seqs.data(), e->d_ss, total, hipMemcpyDeviceToHost));
+    for (int q = 0; q < R; q++) memcpy(mfe_ss + src_off[order[q]], sorted_seqs.data() + off[q], (size_t)h[q]);
+  }
+  if (want_ev) {
+    std::vector<int32_t> t(R);
+    HIP_TRY(hipMemcpy(t.data(), e->d_Ed, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int q = 0; q < R; q++) Ed[order[q]] = t[q];
+  }
   return DRNA_OK;
 }
 
@@ -1020,6 +1089,7 @@ extern "C" int drna_subopt_energy_batch(drna_engine* e, int R, int L, const char
     e->err = "drna_subopt_energy_batch: bad argument (R, L within the engine's limits; seqs and E2 required)";
     return DRNA_ERR_ARG;
   }
+  if (R > e->ws_slots) { e->err = "drna_subopt_energy_batch: batch larger than the workspace (raise DRNA_WS_GB or split the batch)"; return DRNA_ERR_ARG; }
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));
   const int ld = L + 2;
@@ -1146,6 +1216,7 @@ extern "C" int drna_cofold_batch(drna_engine* e, int R, int L, int cut, const ch
     e->err = "drna_cofold_batch: DRNA_NEED_EVAL needs drna_set_targets() with the same L ('&' removed)";
     return DRNA_ERR_ARG;
   }
+  if (R > e->ws_slots) { e->err = "drna_cofold_batch: batch larger than the workspace (raise DRNA_WS_GB or split the batch)"; return DRNA_ERR_ARG; }
   HIP_TRY(hipSetDevice(e->device));
   if (!e->d_F4) HIP_TRY(hipMalloc((void**)&e->d_F4, (size_t)4 * e->max_R * sizeof(double)));
   HIP_TRY(hipMemcpy(e->d_seqs, seqs, (size_t)R * L, hipMemcpyHostToDevice));

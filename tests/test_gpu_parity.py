@@ -779,3 +779,31 @@ def test_lost_pf_helper_costs_milliseconds(eng400, oracle):
     b = eng400.score_batch(seqs, flags)                                      # and the next call uses the helpers again
     assert eng400.get_option("sync_fallbacks") == before + 1 and (b["Epf"].view(np.int64) == ref["Epf"].view(np.int64)).all()
     assert abs(float(ref["Epf"][0]) - oracle.pf(seqs[0])) < EPF_TOL_ORACLE
+
+
+def test_batches_larger_than_the_workspace_go_in_chunks(eng400, oracle, monkeypatch):
+    """The O(L^2) workspaces hold DRNA_WS_GB (default 8) at most; a batch with more sequences than fit goes through them in
+    chunks (ragged call: consecutive runs of the length-sorted order, back to back on the same streams; uniform call: sub-batches).
+    Forced here with a tiny budget: results must equal the unchunked engine's bit for bit, in the caller's order."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(8080)
+    lens = [260, 31, 199, 7, 301, 120, 64, 230, 200, 1, 88, 270, 150, 45, 201, 12] * 3
+    seqs = [_rand(rng, n) for n in lens]
+    flags = E.NEED_PF | E.NEED_MFE
+    ref = eng400.score_ragged(seqs, flags=flags)
+    monkeypatch.setenv("DRNA_WS_GB", "0.1")
+    small = E.Engine(max_R=len(seqs), max_L=301, device=0)
+    try:
+        slots = small.get_option("workspace_slots")
+        assert 8 <= slots < len(seqs) // 2, slots                       # three chunks at least
+        out = small.score_ragged(seqs, flags=flags)
+        assert out["mfe_ss"] == ref["mfe_ss"] and (np.array(out["Emfe"]) == np.array(ref["Emfe"])).all()
+        assert (np.array(out["Epf"]).view(np.int64) == np.array(ref["Epf"]).view(np.int64)).all()
+        uni = [_rand(rng, 130) for _ in range(slots + 9)]
+        a = small.score_batch(uni, flags)
+        b = eng400.score_batch(uni, flags)
+        assert a["mfe_ss"] == b["mfe_ss"] and (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all()
+    finally:
+        small.close()
+    k = 4
+    assert (ref["mfe_ss"][k], int(ref["Emfe"][k])) == oracle.mfe(seqs[k]) and abs(float(ref["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE
