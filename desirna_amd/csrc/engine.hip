@@ -639,6 +639,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       const int s_strips = e->strips;
       const bool s_dual = e->dual, s_help = e->pf_helper;
       e->in_fallback = true; e->strips = 0; e->dual = false; e->pf_helper = false;
+      for (int k = 0; k < 4; k++) e->timing_sum[k] -= e->timing[k];        // the lost attempt (up to the wait budget) is not a kernel time
+      e->timing_sum[4] -= 1.0;
       const int rc = drna_score_batch_device(e, R, L, d_seqs, flags, d_Epf, d_Emfe, d_mfe_ss, d_Ed);
       e->strips = s_strips; e->dual = s_dual; e->pf_helper = s_help; e->in_fallback = false;
       e->sync_fallbacks++;
