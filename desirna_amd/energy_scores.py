@@ -67,115 +67,78 @@ def parse_scoring_functions(scoring_f_str, first_term_only=True):
 
 
 class ScoreSeq:
-    """Per-replica state record; attribute names and order are the reference's (``vars(obj)`` is its CSV schema)."""
+    """Per-replica state record.  The attribute NAMES and their ORDER are the reference's (``vars(obj)`` is its CSV schema,
+    ``utils/energy_scores.py:176-195``) and so are the method names the host code calls; the setters themselves are generated
+    from three small tables below the class instead of being written out one by one."""
+
+    # (attribute, initial value) in the order of the reference's __init__ = the column order of _traj.csv / _results.csv
+    _SCHEMA = (("sequence", None), ("scoring_function", 0), ("replica_num", None), ("temp_shelf", None), ("sim_step", 0),
+               ("edesired_minus_Epf", 0), ("Epf", 0), ("edesired", 0), ("mcc", 0), ("mcc_alt", 0), ("mfe_ss", None),
+               ("subopt_e", 0), ("esubopt_minus_Epf", 0), ("sln_Epf", 0), ("MFE", 0), ("edesired_minus_MFE", 0), ("recall", 0),
+               ("precision", 0), ("edesired2", 0), ("edesired2_minus_Epf", 0))
+    # -sf term -> value taken from the record (reference :376-398); a name that is not listed contributes nothing, as there
+    _TERMS = {"Ed-Epf": lambda r: r.edesired_minus_Epf, "1-MCC": lambda r: r.mcc * 10, "sln_Epf": lambda r: r.sln_Epf,
+              "Ed-MFE": lambda r: r.edesired_minus_MFE, "1-precision": lambda r: r.precision * 10,
+              "1-recall": lambda r: r.recall * 10, "Edef": lambda r: r.ensemble_defect}
 
     def __init__(self, sequence):
+        for name, value in self._SCHEMA:
+            setattr(self, name, value)
         self.sequence = sequence
-        self.scoring_function = 0
-        self.replica_num = None
-        self.temp_shelf = None
-        self.sim_step = 0
-        self.edesired_minus_Epf = 0
-        self.Epf = 0
-        self.edesired = 0
-        self.mcc = 0
-        self.mcc_alt = 0
-        self.mfe_ss = None
-        self.subopt_e = 0
-        self.esubopt_minus_Epf = 0
-        self.sln_Epf = 0
-        self.MFE = 0
-        self.edesired_minus_MFE = 0
-        self.recall = 0
-        self.precision = 0
-        self.edesired2 = 0
-        self.edesired2_minus_Epf = 0
-
-    # setters with the reference's names
-    def get_replica_num(self, rep_num):
-        self.replica_num = rep_num
-
-    def get_temp_shelf(self, temp):
-        self.temp_shelf = temp
-
-    def get_sim_step(self, step):
-        self.sim_step = step
-
-    def get_Epf(self, Epf):
-        self.Epf = Epf
-
-    def get_mfe_ss(self, ss):
-        self.mfe_ss = ss
-
-    def get_edesired(self, e_target):
-        self.edesired = e_target
-
-    def get_edesired_minus_Epf(self, Epf, e_target):
-        self.edesired_minus_Epf = e_target - Epf
-
-    def get_edesired2(self, e_target):
-        self.edesired2 = e_target
-
-    def get_edesired2_minus_Epf(self, Epf, e_target):
-        self.edesired2_minus_Epf = e_target - Epf
-
-    def get_precision(self, precision):
-        self.precision = 1 - precision
-
-    def get_recall(self, recall):
-        self.recall = 1 - recall
-
-    def get_mcc(self, mcc):
-        self.mcc = 1 - mcc
 
     def get_sln_Epf(self):
         self.sln_Epf = (self.Epf + 0.3759 * len(self.sequence) + 5.7534) / 10
 
-    def get_MFE(self, mfe):
-        """reference :350-354 re-folds with RNA.fold(); the engine's fill already produced f5[n]."""
-        self.MFE = mfe
-
     def get_edesired_minus_MFE(self):
         self.edesired_minus_MFE = self.edesired - self.MFE
-
-    def get_subopt_e(self, e_subopt):
-        self.subopt_e = e_subopt
-
-    def get_esubopt_minus_Epf(self, Epf, e_subopt):
-        self.esubopt_minus_Epf = e_subopt - Epf
 
     def get_scoring_function_w_subopt(self):
         self.scoring_function = self.scoring_function - self.esubopt_minus_Epf
 
-    def get_ensemble_defect(self, ensemble_defect):
-        """reference :362-374 runs mfe / rescale / pf / ensemble_defect on a new fold compound; here the value
-        comes from the engine's inside + outside kernels (Engine.ensemble_defect).  The attribute is created on
-        first use exactly as in the reference (it is not part of __init__ there either)."""
-        self.ensemble_defect = ensemble_defect
-
     def get_scoring_function(self, scoring_f):
-        self.scoring_function = 0
+        total = 0
         for function, weight in scoring_f:
-            if function == 'Ed-Epf':
-                self.scoring_function += self.edesired_minus_Epf * weight
-            elif function == '1-MCC':
-                self.scoring_function += self.mcc * 10 * weight
-            elif function == 'sln_Epf':
-                self.scoring_function += self.sln_Epf * weight
-            elif function == 'Ed-MFE':
-                self.scoring_function += self.edesired_minus_MFE * weight
-            elif function == '1-precision':
-                self.scoring_function += self.precision * 10 * weight
-            elif function == '1-recall':
-                self.scoring_function += self.recall * 10 * weight
-            elif function == 'Edef':
-                self.scoring_function += self.ensemble_defect * weight
+            term = self._TERMS.get(function)
+            if term is not None:
+                total += term(self) * weight
+        self.scoring_function = total
 
     def get_scoring_function_w_alt_ss(self):
         self.scoring_function = self.scoring_function + self.edesired2_minus_Epf
 
     def update_scoring_function_w_motifs(self, motif_bonus):
         self.scoring_function += motif_bonus
+
+
+def _install_setters(cls):
+    """``get_<attr>(value)`` stores a value as it comes (MFE: the reference re-folds with RNA.fold(), :350-354, the engine's fill
+    already produced f5[n]; ensemble_defect: the reference runs mfe / rescale / pf / ensemble_defect on a new fold compound,
+    :362-374, here the value comes from the engine's inside + outside kernels -- and the attribute is created on first use, as
+    there); ``get_<attr>(x)`` for precision / recall / mcc stores 1 - x; ``get_<attr>_minus_Epf(Epf, e)`` stores e - Epf."""
+    def plain(attr):
+        def setter(self, value):
+            setattr(self, attr, value)
+        return setter
+
+    def complement(attr):
+        def setter(self, value):
+            setattr(self, attr, 1 - value)
+        return setter
+
+    def minus_epf(attr):
+        def setter(self, Epf, energy):
+            setattr(self, attr, energy - Epf)
+        return setter
+
+    for attr in ("replica_num", "temp_shelf", "sim_step", "Epf", "mfe_ss", "edesired", "edesired2", "MFE", "subopt_e", "ensemble_defect"):
+        setattr(cls, "get_" + attr, plain(attr))
+    for attr in ("precision", "recall", "mcc"):
+        setattr(cls, "get_" + attr, complement(attr))
+    for attr in ("edesired_minus_Epf", "edesired2_minus_Epf", "esubopt_minus_Epf"):
+        setattr(cls, "get_" + attr, minus_epf(attr))
+
+
+_install_setters(ScoreSeq)
 
 
 def score_motifs(seq, sim_options):
