@@ -71,6 +71,7 @@ __device__ __forceinline__ void stores_in_flight() {
   else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
