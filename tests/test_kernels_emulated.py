@@ -263,3 +263,18 @@ def test_mfe_strip_kernel_blocked_splits(blob, oracle):
     assert (st == 0).all()
     for k, s in enumerate(seqs):
         assert (ss[k], int(E[k])) == oracle.mfe(s), s
+
+
+@pytest.mark.parametrize("L,nt", [(30, -257), (64, -257), (96, -1025)])
+def test_pf_helper_workgroup_is_bit_identical(emu, oracle, L, nt):
+    """fold_pf_lds.hpp with a helper workgroup per sequence (far multiloop split points, nt = -257 / -1025: main and helper side
+    by side as OS threads, each with an LDS image of its own, rows and flags through ordinary memory): Epf must equal the
+    one-workgroup kernel's BIT FOR BIT (one canonical summation order whoever computes the far part) and the oracle's to 1e-9."""
+    rng = np.random.default_rng(700 + L)
+    seqs = [_rand(rng, L)] + ([_rand(rng, L, "GC")] if nt == -257 else [])
+    Eh, sth = emu.pf(seqs, nt=nt)
+    E1, st1 = emu.pf(seqs, nt=nt + 1)
+    assert not sth.any() and not st1.any()
+    assert (Eh.view(np.int64) == E1.view(np.int64)).all()
+    for k, s in enumerate(seqs):
+        assert abs(Eh[k] - oracle.pf(s)) < 1e-9, s
