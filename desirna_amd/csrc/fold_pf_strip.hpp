@@ -30,6 +30,61 @@
 
 namespace drna {
 
+// ---- blocked multiloop sums (round 3).  With m = i + tt + 2 the multiloop sum of cell (i, j) is sum_m QM(i, m-1) * QM1(m, j),
+// m = i + TURN + 2 .. j - TURN - 1: a matrix product.  Walked per cell and per diagonal (rounds 1-2) it reads two operands per
+// term out of tables that no longer fit an L2 once a chip is full of strips: 171 MB per 400-nt fold, 43 GB per launch at R = 256,
+// 0.67 of the HBM peak (profiles/r2/strips_pmc.json).  Now cells are grouped in TILES of 16 columns i x 16 columns j (strip-local
+// coordinates, tile row t = (i-1) >> 4, tile column bj = (j-1) >> 4, block distance B = bj - t; first cell due at diagonal
+// d_min = 16 B - 15).  The split points
+//        m_lo = 16 t + 31 + PKT_L  <=  m  <=  16 bj - 13 - PKT_L = m_hi                                    (the FAR range of the tile)
+// have, for EVERY cell of the tile, both operands on diagonals <= d_min - PKT_L, the ones further inside earlier still (one
+// diagonal per split point).  Their part of the product is a dense 16 x (m_hi - m_lo + 1) x 16 product: a TILE WAVE computes it
+// with v_mfma_f64_16x16x4_f64 in chunks of 4 split points (one operand double per lane: 2 loads per 1024 terms instead of 2 per
+// term), spread over the PKT_W steps before d_min FROM THE MIDDLE OUTWARD -- step d_min - 1 - e takes the chunks e cl .. (e+1) cl - 1
+// counted from the low end and e ch .. (e+1) ch - 1 from the high end, so every chunk is taken when its operands are final and
+// visible (diagonals <= step - 2; PKT_L >= 3 suffices: tools/pkt_schedule.py checks every block distance) -- accumulators in
+// registers across the steps, the 256 sums stored to the table DFAR at the end of the window.  The per-diagonal multiloop items
+// keep only the NEAR split points of their cells (m < m_lo or m > m_hi: at most 24 + PKT_L on either side, from rows written or
+// read a few steps ago) and start from the DFAR entry.  Every sum has one fixed order of additions: Epf is reproducible.
+#ifndef PSTRIP_FARK
+#define PSTRIP_FARK 1
+#endif
+#ifndef PSTRIP_SKIP
+#define PSTRIP_SKIP 0        // diagnostic builds only (timing; results wrong): 1 no multiloop items, 2 no bulge / 1xn items, 4 no small shapes, 8 no towers, 16 no tile products
+#endif
+#ifndef DRNA_PKT_W
+#define DRNA_PKT_W 16
+#endif
+#ifndef DRNA_PKT_L
+#define DRNA_PKT_L 4
+#endif
+constexpr int PKT_W = DRNA_PKT_W;                       // steps a tile product is spread over (<= 16: the windows of consecutive block distances do not overlap)
+constexpr int PKT_L = DRNA_PKT_L;                       // the far range's operands are final this many diagonals before d_min
+constexpr int PKT_BMIN = PSTRIP_FARK ? (44 + 2 * PKT_L + 15) / 16 : (1 << 20);   // smallest block distance with a far range
+static_assert(PKT_W >= 1 && PKT_W <= 16, "tile windows must not overlap");
+static_assert(PKT_L >= 3, "a chunk must be final and visible when its step comes");
+
+#ifdef DRNA_EMU
+struct f64x4 { double v[4]; double& operator[](int k) { return v[k]; } double operator[](int k) const { return v[k]; } };
+// v_mfma_f64_16x16x4_f64 as the CDNA4 guide gives it: A[l & 15][l >> 4], B[l >> 4][l & 15], D[(l >> 4) + 4 r][l & 15] in register r
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  const int lane = threadIdx.x & 63, col = lane & 15;
+  for (int k = 0; k < 4; k++) {
+    const double bk = emu_exchange(b, col + 16 * k);
+    for (int r = 0; r < 4; r++) {
+      const double ak = emu_exchange(a, (lane >> 4) + 4 * r + 16 * k);
+      c.v[r] = std::fma(ak, bk, c.v[r]);
+    }
+  }
+  return c;
+}
+#else
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+#endif
+
 template <int NT>
 struct PfStripSmem {
   static constexpr int NW = NT / WAVE;
@@ -85,7 +140,7 @@ __device__ __forceinline__ void strip_tower(SM& sm, double (&G)[PGSLOTS], int d,
       G[qx] = mine ? v : G[qx];
     }
   }
-  const double accG = pf_tower_step(sm, G, par, i * 8, my_g, lane);
+  const double accG = (PSTRIP_SKIP & 8) ? 0.0 : pf_tower_step(sm, G, par, i * 8, my_g, lane);
   if (live) sm.partG[par][my_g][phys] = accG;
   if (!(STRIP_DIAG & 16) && has_down && live && iraw == 1) {               // the tower leaves the strip: its sums go into the record
     double* rec = rec_out + (long long)d * STRIP_REC + 48 + my_g * PGSLOTS;
@@ -244,19 +299,29 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
 
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)QEXT, (short)0, (int)(tab * 8), 0x00020000);
+  double* const DFAR = base + 5 * tab;                                   // far parts of the multiloop sums, [d][global column]
+  const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)DFAR, (short)0, (int)(tab * 8), 0x00020000);
 
   // floating work items of diagonal d (see pf_lds_kernel): multiloop sums from L2 (the qm1 operand may be another strip's: sc1),
   // bulge / 1xn shapes, fixed small shapes.  Output slots are physical tower lanes (i_loc + d/2) mod P.
   auto run_items = [&](const int d, auto with_k) {
     const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
     const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
+    // near split points of the diagonal (tile geometry: see PKT_L): tt = m - 1 - i runs over [TURN+1, 28+PKT_L] and
+    // [d-29-PKT_L, d-TURN-2], every cell masks what belongs to its tile's far range; one range while cells without a far range
+    // exist on the diagonal (d < 16 PKT_BMIN) or the two meet
+    const int tt_end = d - TURN - 2;
+    const bool whole = d < 16 * PKT_BMIN || 28 + PKT_L + 1 >= d - 29 - PKT_L;
+    const int n1 = whole ? tt_end - TURN : 28 + PKT_L - TURN;                 // terms of the first range
+    const int s2 = d - 29 - PKT_L;                                            // first tt of the second
+    const int nterm = whole ? n1 : n1 + tt_end - s2 + 1;
     // a block of 32 cells is dealt to KS = 1, 2, 4 or 8 items by split point, so that no wave walks a long sum as one chain of
-    // dependent L2 round trips while the others idle (a strip keeps its full width while the sums grow with d)
-    int kssh = d > 192 ? 3 : d > 96 ? 2 : d > 48 ? 1 : 0;
+    // dependent L2 round trips while the others idle
+    int kssh = nterm > 192 ? 3 : nterm > 96 ? 2 : nterm > 48 ? 1 : 0;
     if (ncell <= 32 && kssh < 2) kssh = 2;
     const int KS = 1 << kssh, KG = 4 << kssh;
-    const int astep = 8 * KG * ld, cstep = 8 * KG * (ld - 1);
-    const int nK = ((ncell + 31) >> 5) << kssh, nE = (pcnt + 3) >> 2, nX = 3 * ((pcnt + WAVE - 1) / WAVE);
+    const int nK = (PSTRIP_SKIP & 1) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (PSTRIP_SKIP & 2) ? 0 : (pcnt + 3) >> 2,
+              nX = (PSTRIP_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
     // two queues: the multiloop items (16 loads in flight per lane: only waves that hold no tower sums take them), then the shape items
     auto pop = [&]() -> int {
@@ -273,24 +338,32 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
         i = act0 ? i : 1;
         const int ig = i + c0 - 1;                                         // global column
+        // the lane's two cells (i, i + d) and (i + 1, i + 1 + d): same tile row (i is odd), maybe different tile columns
+        const int t16 = (i - 1) & ~15, bj0 = (i + d - 1) & ~15, bj1 = (i + d) & ~15;
+        const bool far0 = bj0 - t16 >= 16 * PKT_BMIN, far1 = bj1 - t16 >= 16 * PKT_BMIN;
+        const int tl0 = far0 ? t16 + 29 + PKT_L - i : d, th0 = far0 ? bj0 - 13 - PKT_L - i : d + 1;
+        const int tl1 = far1 ? t16 + 28 + PKT_L - i : d, th1 = far1 ? bj1 - 14 - PKT_L - i : d + 1;
+        const bool head = (it & (KS - 1)) == 0 && lane < 16;              // the lanes that write slice 0 add the far part
+        f64x2 fv{0.0, 0.0};
+        if (head && (far0 || far1)) fv = buf_load_f64x2_sc1(rsF, (d * ld + ig) * 8, 0);
         double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
-        int tt = TURN + 1 + g;
-        int vA = (tt * ld + ig) * 8;
-        int vC = (int)tab * 8 + ((d - tt - 1) * ld + ig + tt + 1) * 8;
-        for (; tt + 3 * KG <= d - TURN - 2; tt += 4 * KG) {
-          const int vCl = vC - 3 * cstep;
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0v = buf_load_f64x2_sc1(rsQ, vCl, 3 * cstep);
-          const f64x2 a1 = buf_load_f64x2(rsQ, vA, astep), c1v = buf_load_f64x2_sc1(rsQ, vCl, 2 * cstep);
-          const f64x2 a2 = buf_load_f64x2(rsQ, vA, 2 * astep), c2v = buf_load_f64x2_sc1(rsQ, vCl, cstep);
-          const f64x2 a3 = buf_load_f64x2(rsQ, vA, 3 * astep), c3v = buf_load_f64x2_sc1(rsQ, vCl, 0);
-          vA += 4 * astep; vC -= 4 * cstep;
-          p0 += a0.x * c0v.x; q0 += a0.y * c0v.y; p1 += a1.x * c1v.x; q1 += a1.y * c1v.y;
-          p0 += a2.x * c2v.x; q0 += a2.y * c2v.y; p1 += a3.x * c3v.x; q1 += a3.y * c3v.y;
-        }
-        for (; tt <= d - TURN - 2; tt += KG) {
-          const f64x2 a0 = buf_load_f64x2(rsQ, vA, 0), c0v = buf_load_f64x2_sc1(rsQ, vC, 0);
-          p0 += a0.x * c0v.x; q0 += a0.y * c0v.y;
-          vA += astep; vC -= cstep;
+        for (int x = g; x < nterm; x += 4 * KG) {
+          f64x2 a[4], c[4];
+          int tt[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int xu = min(x + u * KG, nterm - 1);
+            tt[u] = xu < n1 ? TURN + 1 + xu : s2 + (xu - n1);
+            a[u] = buf_load_f64x2(rsQ, (tt[u] * ld + ig) * 8, 0);
+            c[u] = buf_load_f64x2_sc1(rsQ, (int)tab * 8 + ((d - tt[u] - 1) * ld + ig + tt[u] + 1) * 8, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool in = x + u * KG < nterm;
+            const bool k0 = in && (tt[u] <= tl0 || tt[u] >= th0), k1 = in && (tt[u] <= tl1 || tt[u] >= th1);
+            const double e0 = k0 ? a[u].x * c[u].x : 0.0, e1 = k1 ? a[u].y * c[u].y : 0.0;
+            if (u & 1) { p1 += e0; q1 += e1; } else { p0 += e0; q0 += e1; }
+          }
         }
         double v0 = p0 + p1, v1 = q0 + q1;
         int slice = lane >> 4;
@@ -305,6 +378,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
           slice = it & (KS - 1);
           writer = lane < 16;
         }
+        if (head) { v0 += far0 ? fv.x : 0.0; v1 += far1 ? fv.y : 0.0; }
         if (writer) {
           if (act0) sm.partK[par][slice][(i + sh) & (P - 1)] = v0;
           if (act1) sm.partK[par][slice][(i + 1 + sh) & (P - 1)] = v1;
@@ -465,6 +539,64 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     }
   };
 
+  // ---- tile products (see PKT_L above).  Tile waves: the floating waves, or the finalize waves of a workgroup that has none;
+  // tile wave f owns the tile rows f, f + NTW, ...  At step k the tiles of block distance B = (k + 15 + PKT_W) >> 4 are in step
+  // g = (k + 15 + PKT_W) & 15 of their window (g < PKT_W; k = d_min - PKT_W + g): operands on diagonals <= d_min - PKT_L <= k - 2.
+  constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * PNG;
+  constexpr int NTW = NFLOAT > 0 ? NFLOAT : NFIN;
+  constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
+  const int tf = NFLOAT > 0 ? aw - NFIN * PNG : wave;
+  f64x4 tacc[TOWN];
+#pragma unroll
+  for (int o = 0; o < TOWN; o++) tacc[o] = f64x4{0.0, 0.0, 0.0, 0.0};
+  constexpr int PKT_DEPTH = 8;              // chunks in flight (16 loads)
+  auto tile_job = [&](const int k) {
+    const int x = k + 15 + PKT_W, B = x >> 4, g = x & 15;
+    if (!PSTRIP_FARK || (PSTRIP_SKIP & 16) || g >= PKT_W || B < PKT_BMIN) return;
+    const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int o = 0; o < TOWN; o++) {
+      const int t = tf + NTW * o, bj = t + B;
+      if (16 * t >= wid || 16 * bj + 1 > n_loc) continue;                   // (wave-uniform) no such tile in this strip / triangle
+      const int m_lo = 16 * t + 31 + PKT_L, m_hi = 16 * bj - 13 - PKT_L;
+      const int nch = (m_hi - m_lo + 4) >> 2, nl = (nch + 1) >> 1, nh = nch >> 1;
+      const int cl = (nl + PKT_W - 1) / PKT_W, ch = (nh + PKT_W - 1) / PKT_W, e = PKT_W - 1 - g;
+      const int lo0 = e * cl, nlo = max(0, min(nl, lo0 + cl) - lo0), hi0 = e * ch, nhi = max(0, min(nh, hi0 + ch) - hi0);
+      const int ncs = nlo + nhi;                                              // chunks of this step: low side first
+      // rows / columns beyond the strip or the sequence repeat the last one: their sums are never stored
+      const int il = min(16 * t + 1 + r, wid), jl = min(16 * bj + 1 + r, n_loc);
+      const int oA = ((-1 - il) * ld + c0 - 1 + il) * 8, oB = (int)tab * 8 + (jl * ld + c0 - 1) * 8;     // + m * (ld * 8)  |  - m * (ld - 1) * 8
+      f64x4 acc = tacc[o];
+      if (g == 0) acc = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < ncs; c += PKT_DEPTH) {
+        double a[PKT_DEPTH], b[PKT_DEPTH];
+#pragma unroll
+        for (int u = 0; u < PKT_DEPTH; u++) {
+          a[u] = 0.0; b[u] = 0.0;
+          if (c + u < ncs) {
+            const int cid = c + u < nlo ? lo0 + c + u : nch - 1 - (hi0 + c + u - nlo);
+            const int m = m_lo + 4 * cid + kk, mc = min(m, m_hi);
+            a[u] = buf_load_f64(rsQ, oA + mc * (ld * 8), 0);                 // QM(i, m - 1): own columns
+            b[u] = buf_load_f64_aux(rsQ, oB - mc * ((ld - 1) * 8), 0);       // QM1(m, j): maybe another strip's
+            if (m > m_hi) a[u] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PKT_DEPTH; u++)
+          if (c + u < ncs) acc = mfma_f64_16x16x4(a[u], b[u], acc);
+      }
+      tacc[o] = acc;
+      if (g == PKT_W - 1) {
+        const int jj = 16 * bj + 1 + r;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int ii = 16 * t + 1 + kk + 4 * rr;
+          if (ii <= wid && jj <= n_loc) DFAR[(long long)(jj - ii) * ld + c0 - 1 + ii] = acc[rr];
+        }
+      }
+    }
+  };
+
   bool failed = false;
   if (fin) {
     // ================= finalize waves: diagonal d = k-1 at step k
@@ -543,6 +675,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         }
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
+      if (NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});            // help the sweep of diagonal k
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
@@ -558,7 +691,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   } else if (!pinned) {
     // ================= floating waves: items only
     for (int k = TURN + 1; k <= n_loc; k++) {
-      if (k < n_loc) run_items(k, std::true_type{});
+      if (k < n_loc) { tile_job(k); run_items(k, std::true_type{}); }
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }

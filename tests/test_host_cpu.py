@@ -93,3 +93,17 @@ def test_bench_launches_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
                        env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and sorted(x.name for x in tmp_path.iterdir()) == ["rank1.json"]      # one process: this rank only
+
+
+def test_tile_product_schedule_never_reads_an_unfinished_operand():
+    """fold_pf_strip.hpp deals the chunks of a tile's far range to the 16 steps before the tile is due, from the middle outward
+    (tools/pkt_schedule.py restates the plan): every chunk exactly once, and only when both operands are final and visible
+    (diagonals <= step - 2) -- for the shipped constants and the smallest lead that works; one diagonal less must fail."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pkt_schedule", os.path.join(ROOT, "tools", "pkt_schedule.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    src = open(os.path.join(ROOT, "desirna_amd", "csrc", "fold_pf_strip.hpp")).read()
+    import re
+    W = int(re.search(r"#define DRNA_PKT_W (\d+)", src).group(1)); L = int(re.search(r"#define DRNA_PKT_L (\d+)", src).group(1))
+    assert m.check(W, L) == 0 and m.check(W, 3) == 0 and m.check(8, 3) == 0
+    assert m.check(W, 2) > 0

@@ -237,6 +237,21 @@ def test_pf_strip_kernel(emu, oracle):
         assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
 
 
+@pytest.mark.parametrize("flags,tag", [((), ""), (("-DDRNA_PKT_W=6", "-DDRNA_PKT_L=3"), "_pktw6")])
+def test_pf_strip_kernel_blocked_sums(blob, oracle, flags, tag):
+    """The blocked multiloop sums of fold_pf_strip.hpp (16 x 16 tiles of cells; the far split points as v_mfma_f64_16x16x4_f64
+    products spread over the PKT_W steps before the tile is due, here in the emulation's restatement of the instruction's
+    operand layout; near split points masked per cell in the per-diagonal items).  150 nt in three strips of 50 columns: tiles
+    of block distance 5 .. 9 have far ranges of up to 90 split points; a second window length moves every boundary."""
+    e = Emu(blob, flags=flags, tag=tag) if flags else Emu(blob)
+    rng = np.random.default_rng(4113)
+    seqs = [_rand(rng, 150, "GGCCAU"), _rand(rng, 150, "ACGU")]
+    Ep, st = e.pf_strip(seqs, 3, nt=256, calls=1)
+    assert (st == 0).all()
+    for k, s in enumerate(seqs):
+        assert abs(Ep[k] - oracle.pf(s)) < 1e-9, s
+
+
 def test_mfe_strip_kernel(emu, oracle):
     """fold_mfe_strip.hpp on the CPU: per pseudoknot round the two strips of a sequence side by side, then the traceback
     "launch" on the tables they left behind; energies and pk-annotated structures must equal the oracle's; a bad character is
