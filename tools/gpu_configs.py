@@ -26,13 +26,24 @@ def run(name, tg, R, flags, alts=(), reps=4):
     eng.close()
 
 
-run("config2_L100_R64_mfe_only", bench.load_target("eteV1_92.txt"), 64, E.NEED_MFE | E.NEED_EVAL)
-run("config3_L200_R64", bench.load_target("eteV1_69.txt"), 64, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
-run("config3_shape_R128", bench.load_target("eteV1_69.txt"), 128, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
-run("config3_shape_R256", bench.load_target("eteV1_69.txt"), 256, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+ONLY = os.environ.get("CONFIGS_ONLY", "")          # "4": config 4 only; "5": config 5 only
+
+
+def run_if(tag, *a, **k):
+    if not ONLY or ONLY == tag:
+        run(*a, **k)
+
+
+run_if("2", "config2_L100_R64_mfe_only", bench.load_target("eteV1_92.txt"), 64, E.NEED_MFE | E.NEED_EVAL)
+run_if("3", "config3_L200_R64", bench.load_target("eteV1_69.txt"), 64, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+run_if("3", "config3_shape_R128", bench.load_target("eteV1_69.txt"), 128, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
+run_if("3", "config3_shape_R256", bench.load_target("eteV1_69.txt"), 256, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL)
 tg = bench.load_target("eteV1_53.txt")
 pk = list(tg)
-run("config5_L400_R128_pk_alt", tg, 128, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL | E.NEED_PK, alts=[tg, tg], reps=3)
+run_if("5", "config5_L400_R128_pk_alt", tg, 128, E.NEED_MFE | E.NEED_PF | E.NEED_EVAL | E.NEED_PK, alts=[tg, tg], reps=3)
+if ONLY and ONLY != "4":
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 # config 4: the whole Eterna100-V1 set, 32 replicas per puzzle, one ragged call
 import csv
 rows = list(csv.DictReader(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "eterna_v1_solutions.csv"))))
