@@ -27,7 +27,7 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #define MSTRIP_LEAD 0
 #endif
 #ifndef MSTRIP_SKIP
-#define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize
+#define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize, 128 split items without their second operand's loads, 256 those loads plain
 #endif
 
 #ifndef MSTRIP_KU
@@ -439,7 +439,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           for (int u = 0; u < U; u++) {
             const bool on = u < nvalid;
             a[u] = buf_load_i32x4(rsF, on ? vA + u * astep : vA, 0);
-            c[u] = buf_load_i32x4_sc1(rsF, on ? vC - u * cstep : vC, 0);
+            c[u] = (MSTRIP_SKIP & 128) ? a[u] : (MSTRIP_SKIP & 256) ? buf_load_i32x4(rsF, on ? vC - u * cstep : vC, 0) : buf_load_i32x4_sc1(rsF, on ? vC - u * cstep : vC, 0);
           }
 #pragma unroll
           for (int u = 0; u < U; u++) {
