@@ -52,6 +52,13 @@ namespace drna {
 #ifndef PSTRIP_SKIP
 #define PSTRIP_SKIP 0        // diagnostic builds only (timing; results wrong): 1 no multiloop items, 2 no bulge / 1xn items, 4 no small shapes, 8 no towers, 16 no tile products
 #endif
+#ifndef DRNA_PKT_NB
+#define DRNA_PKT_NB 4
+#endif
+#ifndef DRNA_PKT_SVC
+#define DRNA_PKT_SVC 1
+#endif
+constexpr bool PKT_SVC = DRNA_PKT_SVC != 0;             // the service waves take tile rows too
 #ifndef DRNA_PKT_W
 #define DRNA_PKT_W 16
 #endif
@@ -347,18 +354,19 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         f64x2 fv{0.0, 0.0};
         if (head && (far0 || far1)) fv = buf_load_f64x2_sc1(rsF, (d * ld + ig) * 8, 0);
         double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
-        for (int x = g; x < nterm; x += 4 * KG) {
-          f64x2 a[4], c[4];
-          int tt[4];
+        constexpr int NB = DRNA_PKT_NB;        // terms per lane and round trip
+        for (int x = g; x < nterm; x += NB * KG) {
+          f64x2 a[NB], c[NB];
+          int tt[NB];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < NB; u++) {
             const int xu = min(x + u * KG, nterm - 1);
             tt[u] = xu < n1 ? TURN + 1 + xu : s2 + (xu - n1);
             a[u] = buf_load_f64x2(rsQ, (tt[u] * ld + ig) * 8, 0);
             c[u] = buf_load_f64x2_sc1(rsQ, (int)tab * 8 + ((d - tt[u] - 1) * ld + ig + tt[u] + 1) * 8, 0);
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < NB; u++) {
             const bool in = x + u * KG < nterm;
             const bool k0 = in && (tt[u] <= tl0 || tt[u] >= th0), k1 = in && (tt[u] <= tl1 || tt[u] >= th1);
             const double e0 = k0 ? a[u].x * c[u].x : 0.0, e1 = k1 ? a[u].y * c[u].y : 0.0;
@@ -543,9 +551,9 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   // tile wave f owns the tile rows f, f + NTW, ...  At step k the tiles of block distance B = (k + 15 + PKT_W) >> 4 are in step
   // g = (k + 15 + PKT_W) & 15 of their window (g < PKT_W; k = d_min - PKT_W + g): operands on diagonals <= d_min - PKT_L <= k - 2.
   constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * PNG;
-  constexpr int NTW = NFLOAT > 0 ? NFLOAT : NFIN;
+  constexpr int NTW = NFLOAT > 0 ? NFLOAT + (PKT_SVC ? NSVC : 0) : NFIN;    // (with the service waves: one tile row per tile wave)
   constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
-  const int tf = NFLOAT > 0 ? aw - NFIN * PNG : wave;
+  const int tf = NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * PNG : NFLOAT + wave - NFIN) : wave;
   f64x4 tacc[TOWN];
 #pragma unroll
   for (int o = 0; o < TOWN; o++) tacc[o] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -684,6 +692,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     // ================= service waves
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (wave == w_svcA) service_a(k); else service_b(k);
+      if (PKT_SVC && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
