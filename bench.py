@@ -271,9 +271,17 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: running %d ranks\n" % (args.gpus, world, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # DRNA_BENCH_FORCE_DIST=1: run the exchange step's collectives (all-gather, barrier, max all-reduce) at N = 1 too -- a
+    # one-rank communicator over RCCL on the one GPU a test box has (tests/test_gpu_parity.py); the N > 1 path is the same code
+    multi = world > 1 or os.environ.get("DRNA_BENCH_FORCE_DIST", "0") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     # DRNA_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: the ranks share the card (local_rank modulo the device
     # count) and the score gather goes through host tensors, so the launch contract (env, barriers, max over ranks, one JSON
     # line from rank 0) can be exercised without RCCL.  Real runs use the default, RCCL, one rank per GPU.
@@ -283,7 +291,7 @@ def main():
     elif torch.cuda.device_count() < world:
         raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (DRNA_BENCH_BACKEND=gloo rehearses the "
                          "launch on fewer)" % (world, world, torch.cuda.device_count()))
-    if world > 1:
+    if multi:
         if backend == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
@@ -318,13 +326,13 @@ def main():
     d_Emfe = torch.zeros(R, dtype=torch.int32, device=dev)
     d_ss = torch.zeros(R * L, dtype=torch.uint8, device=dev)
     d_Ed = torch.zeros(R, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(R * world, dtype=torch.float64, device=cdev) if world > 1 else None
+    gathered = torch.zeros(R * world, dtype=torch.float64, device=cdev) if multi else None
     torch.cuda.synchronize()
 
     def step(k, last):
         eng.score_batch_device(d_seqs.data_ptr(), R, L, flags, d_Epf.data_ptr(), d_Emfe.data_ptr(),
                                d_ss.data_ptr(), d_Ed.data_ptr())
-        if world > 1 and (last or (k + 1) % args.exchange_every == 0):
+        if multi and (last or (k + 1) % args.exchange_every == 0):
             score = d_Ed.to(torch.float64) / 100.0 - d_Epf          # Ed - Epf, the default -sf term
             dist.all_gather_into_tensor(gathered, score.to(cdev))
             torch.cuda.current_stream().synchronize()               # d_Ed / d_Epf are read: the next step's kernels (other streams) overwrite them
@@ -332,7 +340,7 @@ def main():
     for k in range(args.warmup):
         step(k, False)
     tk = {"mfe": 0.0, "pf": 0.0, "eval": 0.0, "total": 0.0}
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     eng.timing_sums(reset=True)                     # the engine sums its HIP-event kernel times over the timed calls itself
@@ -340,10 +348,10 @@ def main():
     for k in range(args.steps):
         step(k, k == args.steps - 1)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -356,7 +364,7 @@ def main():
         dom = "pf" if tk["pf"] >= tk["mfe"] else "mfe"
         out = {
             "metric": "replica-folds/sec (MFE+PF, L=%d, R=%d)" % (L, R),
-            "value": folds / dt, "unit": "replica-folds/s", "n_gpus": world, "steps": args.steps,
+            "value": folds / dt, "unit": "replica-folds/s", "n_gpus": world, "collectives": (backend if multi else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32 (MFE) + f64 (PF)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Eterna100-V1 #%s target (L=%d), R=%d %s-random sequences per GPU, "
@@ -390,7 +398,7 @@ def main():
                 print(json.dumps(out))
                 raise SystemExit("bench: GPU results differ from the oracle")
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -807,3 +807,21 @@ def test_batches_larger_than_the_workspace_go_in_chunks(eng400, oracle, monkeypa
         small.close()
     k = 4
     assert (ref["mfe_ss"][k], int(ref["Emfe"][k])) == oracle.mfe(seqs[k]) and abs(float(ref["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE
+
+
+def test_bench_exchange_step_over_rccl_single_rank():
+    """bench.py's exchange step (all-gather of the replica scores, barriers, max all-reduce of the time: reference
+    utils/replica_exchange_monte_carlo.py:113-173) through RCCL itself: DRNA_BENCH_FORCE_DIST=1 builds a one-rank communicator
+    on the one GPU this box has and runs the same collectives on device tensors that N ranks run; the line must say so and
+    carry the same metric."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DRNA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DRNA_BENCH_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                        "--exchange-every", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["collectives"] == "nccl" and d["n_gpus"] == 1 and d["metric"] and d["value"] > 0
