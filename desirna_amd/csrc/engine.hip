@@ -108,6 +108,10 @@ struct drna_engine {
   int pflags_cap = 0, pfh_epoch = 0;
   int last_wgs = 0;               // fold workgroups of the last drna_score_batch call (partition function + MFE kernels, resident side by side)
   int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
+  // A GPU shared with another process (or a runtime that stops dispatching in block order) loses partners call after call, and
+  // every lost call costs its wait budget before it is redone.  Three fallbacks in a row switch the multi-workgroup paths off
+  // for the next SOLO_CALLS calls (option "solo_calls_left"); then one call probes again.  Any set_option of the paths resets it.
+  int fallback_streak = 0, solo_left = 0;
   bool in_fallback = false;
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
   int32_t* d_srec = nullptr;      // MFE strips: exchange records and list counts, srec_stride int32 per sequence
@@ -192,6 +196,7 @@ static int next_strip_epoch(drna_engine* e) {
 }
 
 // nseq sequences (slots first_slot ...; idx = their sequence numbers or null) by S strips each
+constexpr int SOLO_CALLS = 1000;      // calls with one workgroup per fold after three lost calls in a row (see fallback_streak)
 static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {
   StripLink lk;
   lk.flags = e->d_sflags + (size_t)first_slot * STRIP_MAXS * 32;
@@ -336,6 +341,7 @@ extern "C" int drna_abi_version(void) { return DRNA_ABI_VERSION; }
 
 extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
+  if (!strcmp(name, "dual") || !strcmp(name, "strips") || !strcmp(name, "pf_helper")) { e->fallback_streak = 0; e->solo_left = 0; }
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   if (!strcmp(name, "pf_helper")) { e->pf_helper = value != 0; return DRNA_OK; }
@@ -362,6 +368,7 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!strcmp(name, "strips")) { *value = e->strips; return DRNA_OK; }
   if (!strcmp(name, "pf_helper")) { *value = e->pf_helper ? 1 : 0; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
+  if (!strcmp(name, "solo_calls_left")) { *value = e->solo_left; return DRNA_OK; }
   if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
   if (!strcmp(name, "workspace_slots")) { *value = e->ws_slots; return DRNA_OK; }
   if (!strcmp(name, "flag_resets")) { *value = e->flag_resets; return DRNA_OK; }
@@ -426,6 +433,15 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   if (want_ev && (e->n_targets < 1 || e->L_targets != L)) {
     e->err = "drna_score_batch: DRNA_NEED_EVAL needs drna_set_targets() with the same L";
     return DRNA_ERR_ARG;
+  }
+  if (!e->in_fallback && e->solo_left > 0) {             // after repeated lost partners: one workgroup per fold for a while
+    const int s_strips = e->strips;
+    const bool s_dual = e->dual, s_help = e->pf_helper;
+    e->in_fallback = true; e->strips = 0; e->dual = false; e->pf_helper = false;
+    const int rc = drna_score_batch_device(e, R, L, d_seqs, flags, d_Epf, d_Emfe, d_mfe_ss, d_Ed);
+    e->strips = s_strips; e->dual = s_dual; e->pf_helper = s_help; e->in_fallback = false;
+    e->solo_left--;
+    return rc;
   }
   HIP_TRY(hipSetDevice(e->device));
   if (R > e->ws_slots) {
@@ -644,6 +660,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       const int rc = drna_score_batch_device(e, R, L, d_seqs, flags, d_Epf, d_Emfe, d_mfe_ss, d_Ed);
       e->strips = s_strips; e->dual = s_dual; e->pf_helper = s_help; e->in_fallback = false;
       e->sync_fallbacks++;
+      if (++e->fallback_streak >= 3) { e->fallback_streak = 0; e->solo_left = SOLO_CALLS; }
       return rc;
     }
     if (st == ST_SYNC) {
@@ -660,6 +677,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->err = buf;
     return DRNA_ERR_INTERNAL;
   }
+  if (!e->in_fallback) e->fallback_streak = 0;          // nobody lost anybody
   return DRNA_OK;
 }
 
@@ -876,6 +894,14 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     e->err = "drna_score_ragged: bad argument (R within the engine's limit; output pointers for every requested flag)";
     return DRNA_ERR_ARG;
   }
+  if (!e->in_fallback && e->solo_left > 0) {             // (see drna_score_batch_device)
+    const int s_strips = e->strips;
+    e->in_fallback = true; e->strips = 0;
+    const int rc = drna_score_ragged(e, R, lens, seqs, target_of, flags, Epf, Emfe, mfe_ss, Ed);
+    e->strips = s_strips; e->in_fallback = false;
+    e->solo_left--;
+    return rc;
+  }
   // The batch is folded in SORTED order, longest first: position q on the device is sequence order[q] of the caller.  Then
   // (a) the three classes -- strips (n > 200), general kernels, LDS-resident kernels (n <= 200) -- are ranges of q, and (b) a
   // batch larger than the workspaces (ws_slots sequences, DRNA_WS_GB) goes through them in CHUNKS of consecutive q: chunk c
@@ -1047,6 +1073,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
       const int rc = drna_score_ragged(e, R, lens, seqs, target_of, flags, Epf, Emfe, mfe_ss, Ed);
       e->strips = s_strips; e->in_fallback = false;
       e->sync_fallbacks++;
+      if (++e->fallback_streak >= 3) { e->fallback_streak = 0; e->solo_left = SOLO_CALLS; }
       return rc;
     }
     char buf[160];
@@ -1057,6 +1084,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     e->err = buf;
     return st == ST_BAD_CHAR ? DRNA_ERR_SEQUENCE : st == ST_PF_RANGE ? DRNA_ERR_PF_RANGE : DRNA_ERR_INTERNAL;
   }
+  if (!e->in_fallback) e->fallback_streak = 0;
   // results back in the caller's order
   if (want_pf) {
     std::vector<double> t(R);

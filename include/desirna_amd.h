@@ -192,7 +192,9 @@ int drna_set_option(drna_engine *e, const char *name, int value);
 /* reads an option back ("dual", "strips"), or the counter "sync_fallbacks": calls in which a fold by several workgroups lost a
  * partner (a bounded wait expired -- HIP promises no dispatch order) and which were therefore redone, transparently, with one
  * workgroup per fold.  Option "strip_fault" = 1 injects such a loss into every strip launch (tests).  "last_workgroups": fold
- * workgroups (partition function + MFE kernels, resident side by side) of the last drna_score_batch call. */
+ * workgroups (partition function + MFE kernels, resident side by side) of the last drna_score_batch call.  "solo_calls_left":
+ * after three such calls in a row (a GPU shared with another process) the engine folds with one workgroup per fold for the
+ * next 1000 calls, then probes again; setting "dual", "strips" or "pf_helper" ends that at once. */
 int drna_get_option(const drna_engine *e, const char *name, int *value);
 
 /* diagnostics (engine created with DRNA_STRIP_DEBUG=1 in the environment): start / end wall clocks (100 MHz ticks) of the MFE

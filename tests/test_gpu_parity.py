@@ -781,6 +781,38 @@ def test_lost_pf_helper_costs_milliseconds(eng400, oracle):
     assert abs(float(ref["Epf"][0]) - oracle.pf(seqs[0])) < EPF_TOL_ORACLE
 
 
+def test_repeated_lost_partners_switch_the_multi_workgroup_paths_off_for_a_while(eng400):
+    """A GPU shared with another process loses partners call after call, and every lost call costs its wait budget before it is
+    redone (round-2 advisor finding).  Three fallbacks in a row: the engine folds with one workgroup per fold for the next 1000
+    calls (no wait, no fallback), results unchanged; setting one of the path options ends that at once."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(77003)
+    seqs = [_rand(rng, 200) for _ in range(6)]
+    flags = E.NEED_PF | E.NEED_MFE
+    ref = eng400.score_batch(seqs, flags)
+    wgs = eng400.get_option("last_workgroups")
+    before = eng400.get_option("sync_fallbacks")
+    try:
+        eng400.set_option("helper_fault", 1)
+        for k in range(3):
+            a = eng400.score_batch(seqs, flags)
+            assert eng400.get_option("sync_fallbacks") == before + k + 1
+        INJECTED_FALLBACKS.append(3)
+        assert eng400.get_option("solo_calls_left") == 1000
+        b = eng400.score_batch(seqs, flags)                      # the fault is still on: nobody waits for a helper now
+        assert eng400.get_option("sync_fallbacks") == before + 3 and eng400.get_option("solo_calls_left") == 999
+        assert eng400.get_option("last_workgroups") < wgs
+    finally:
+        eng400.set_option("helper_fault", 0)
+    eng400.set_option("pf_helper", 1)                            # any path option: probe again at once
+    assert eng400.get_option("solo_calls_left") == 0
+    c = eng400.score_batch(seqs, flags)
+    assert eng400.get_option("last_workgroups") == wgs and eng400.get_option("sync_fallbacks") == before + 3
+    for r in (a, b, c):
+        assert r["mfe_ss"] == ref["mfe_ss"] and (r["Emfe"] == ref["Emfe"]).all()
+        assert (r["Epf"].view(np.int64) == ref["Epf"].view(np.int64)).all()
+
+
 def test_batches_larger_than_the_workspace_go_in_chunks(eng400, oracle, monkeypatch):
     """The O(L^2) workspaces hold DRNA_WS_GB (default 8) at most; a batch with more sequences than fit goes through them in
     chunks (ragged call: consecutive runs of the length-sorted order, back to back on the same streams; uniform call: sub-batches).
