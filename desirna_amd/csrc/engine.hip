@@ -33,6 +33,10 @@ using namespace drna;
 
 static std::string g_create_error;
 
+#ifndef DRNA_MFE_FARK_MIN_STRIPS
+#define DRNA_MFE_FARK_MIN_STRIPS 6
+#endif
+constexpr int MFE_FARK_MIN_STRIPS = DRNA_MFE_FARK_MIN_STRIPS;   // (measured: tools/time_strip_variants.py)
 struct drna_engine {
   int device = 0, max_R = 0, max_L = 0, nt = 1024, cus = 0;
   bool lds_path = true;   // LDS-resident kernels when n fits (DRNA_PATH=global forces the general path)
@@ -100,6 +104,7 @@ struct drna_engine {
   int strip_epoch = 0;            // grows by one per launch; flags and epoch go back to zero at STRIP_EPOCH_RESET
   int flag_resets = 0;            // times the hand-over flags were zeroed because an epoch neared the compare range
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
+  int mfe_fark_min_strips = MFE_FARK_MIN_STRIPS;   // option "mfe_fark_min_strips": MFE strips fold in blocked form from this many strips on
   int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
   bool helper_fault = false;      // tests: the helper workgroups of the partition function leave at once (a lost partner)
   bool pf_helper = true;          // small batches: a helper workgroup per sequence computes the far multiloop split points of the
@@ -218,9 +223,11 @@ static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, 
   lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
   lk.base = next_strip_epoch(e);
   lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.r0 = r0; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
+  lk.fark = S >= e->mfe_fark_min_strips;           // blocked multiloop splits for the long folds (fold_mfe_strip.hpp, MKT_L)
   lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
   lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
-  hipLaunchKernelGGL(mfe_strip_kernel<1024>, dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
+  if (lk.fark) hipLaunchKernelGGL((mfe_strip_kernel<1024, true>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
+  else hipLaunchKernelGGL((mfe_strip_kernel<1024, false>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
   hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round, r0);
 }
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
@@ -347,6 +354,7 @@ extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!strcmp(name, "pf_helper")) { e->pf_helper = value != 0; return DRNA_OK; }
   if (!strcmp(name, "helper_fault")) { e->helper_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
+  if (!strcmp(name, "mfe_fark_min_strips")) { e->mfe_fark_min_strips = value < 1 ? 1 : value; return DRNA_OK; }
   if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
   if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; e->pfh_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
   e->err = std::string("drna_set_option: unknown option ") + name;

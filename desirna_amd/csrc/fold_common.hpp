@@ -307,6 +307,7 @@ struct StripLink {
   int S = 0;                 // strips per sequence
   int pad = 0;               // empty blocks per sequence behind its strips (see strip_pad)
   int fault = 0;             // tests: the top strip of every sequence gives up at once (exercises the engine's fallback)
+  int fark = 0;              // MFE strips: multiloop splits in blocked form (tile products + near split points; fold_mfe_strip.hpp)
   const int* idx = nullptr;  // sequence slot -> sequence (ragged batches), or null: slot q is sequence q + r0
   int r0 = 0;
   int* dbg = nullptr;        // diagnostics: 8 words per sequence slot, written by a strip whose wait failed

@@ -33,29 +33,38 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #ifndef MSTRIP_KU
 #define MSTRIP_KU 8       // split points per lane and round trip in the big batches (2 x 16-byte loads each)
 #endif
-#ifndef MSTRIP_FARK
-#define MSTRIP_FARK 0        // 1 = multiloop splits in blocked form (see far_blocks): correct, not yet faster; 0 = every split point per diagonal
+// ---- blocked multiloop splits (StripLink::fark, chosen per launch by the engine: long folds).  With m = i + tt + 2 the split
+// minimum of cell (i, j) is min_m fML(i, m-1) + fML(m, j), m = i + TURN + 2 .. j - TURN - 1: a (min,+) matrix product.  Same
+// geometry and schedule as the blocked sums of the partition function (fold_pf_strip.hpp, which has the derivation): tiles of
+// 16 x 16 cells in strip-local coordinates, the FAR range m_lo = 16 t + 31 + MKT_L .. 16 bj - 13 - MKT_L = m_hi of tile (t, bj)
+// computed by a tile wave in chunks of 4 split points over the MKT_W steps before the tile's first cell is due, from the middle
+// outward; near split points masked per cell in the per-diagonal items.  There is no matrix instruction for (min,+): a chunk is
+// 2 loads (lane (h, x): fML(i_min + h + 4 (x >> 2), m0 + (x & 3) - 1) and fML(m0 + h, j_min + x)), 4 ds_bpermute that bring a
+// lane the four second operands of its column, and 16 add + min pairs whose first operand is a DPP row broadcast
+// (row_newbcast) -- 1024 terms for ~60 instructions and 2 loads, against 8 16-byte loads per 1024 terms per diagonal.  The
+// accumulators (4 per lane) stay in registers over the window; the 256 minima of a tile go to an LDS slot (two per tile row:
+// the tile is read for 31 diagonals, the next one of its row is due 16 later).  Round 2's form of this (-DMSTRIP_FARK: tile
+// products through LDS staging, far items in the queue, lead 4 + 2 t) was slower than the plain items at every length and is gone.
+#ifndef DRNA_MKT_W
+#define DRNA_MKT_W 16
 #endif
-// ---- blocked multiloop splits.  With k = i + tt + 1 the split minimum of cell (i, j) is min_k F[i, k-1] + F[k, j], k = i+5 .. j-4:
-// a (min,+) matrix product.  Cells are grouped in tiles of 16 columns i (anchored at the strip's first column) x 16 columns j
-// (anchored at multiples of 16); the part of the product over the 16-blocks of k that lie well inside -- k >= imax + lat + 17 and
-// k + 15 <= jmin - lat - 16 -- has operands that are final `lat` diagonals before the tile's first cell is due, so it is computed
-// there as dense 16 x 16 x 16 tile products (both operand tiles staged through LDS once: 1 load per 16 terms instead of 2 per
-// term) into an LDS slot of the tile; only the <= ~100 split points next to i and to j stay in the per-diagonal items.
-// lat differs by tile row (4 + 2 t) so that the tile rows of a strip have their turn at different steps.
-__host__ __device__ inline int far_lat(int t) { return 4 + 2 * (t & 7); }
-__host__ __device__ inline bool far_blocks(int c0, int c1, int t, int bj, int& bk_lo, int& bk_hi) {
-  const int imax = (c0 + 16 * t + 15 < c1 ? c0 + 16 * t + 15 : c1), lat = far_lat(t);
-  bk_lo = (imax + lat + 17 + 15) >> 4;
-  const int hi = 16 * bj - lat - 31;
-  bk_hi = hi >= 0 ? hi >> 4 : -1;
-  return bk_hi >= bk_lo;
+#ifndef DRNA_MKT_L
+#define DRNA_MKT_L 4
+#endif
+constexpr int MKT_W = DRNA_MKT_W, MKT_L = DRNA_MKT_L;
+constexpr int MKT_BMIN = (44 + 2 * MKT_L + 15) / 16;          // smallest block distance with a far range
+static_assert(MKT_W >= 1 && MKT_W <= 16 && MKT_L >= 3, "see tools/pkt_schedule.py");
+
+// lane (row, n) of the 16-lane row: the value lane n of the same row holds (DPP row_newbcast on gfx90a and later)
+template <int N>
+__device__ __forceinline__ int row_bcast_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false); }
+__device__ __forceinline__ int lane_fetch_i32(int v, int src_lane) {
+#ifdef DRNA_EMU
+  return emu_exchange(v, src_lane);
+#else
+  return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);
+#endif
 }
-#ifndef DRNA_FAR_CH
-#define DRNA_FAR_CH 4
-#endif
-constexpr int FAR_CH = DRNA_FAR_CH;          // k-blocks per far item
-constexpr int FAR_TAB = 128;       // far items per step at most
 
 template <int NT>
 struct MfeStripSmem {
@@ -79,11 +88,7 @@ struct MfeStripSmem {
   int dml[4 * RS];               // decomposition minima of the last 4 diagonals
   int fmlrow[2][RS];             // fML of the last two diagonals
   int accG[2][P], accI[2][P], accK[2][P];
-  // blocked multiloop splits (MSTRIP_FARK; one element each when off)
-  int dfar[MSTRIP_FARK ? P / 16 : 1][MSTRIP_FARK ? 4 : 1][MSTRIP_FARK ? 256 : 1];   // far part of the split minimum of a tile: [tile row][16-block of j & 3][16 x 16 cells]
-  int fstage[MSTRIP_FARK ? NW : 1][MSTRIP_FARK ? 16 * 17 + 256 : 1];              // per wave: the two operand tiles of a tile product
-  int far_tab[2][MSTRIP_FARK ? FAR_TAB : 1];   // far items of the step: tile row | j-block << 4 | first k-block << 12 | k-blocks << 20
-  int far_cnt[2];
+  int dfar[(P + 15) / 16][2][256];   // far part of the split minimum of a tile: [tile row][tile column & 1][16 x 16 cells]
   int gimp[2][NG][GSLOTS + 2];   // minima of the tower that enters the strip, staged by the service wave
   int xtab[64 + 1024 + 128 + 128];
   int plist[2][NL];
@@ -170,7 +175,7 @@ __device__ __forceinline__ void mstrip_tower(SM& sm, int (&G)[GSLOTS], int d, in
 }
 
 // one strip of one sequence, one round.  q = sequence slot of the launch, s = strip (0 = highest columns)
-template <int NT>
+template <int NT, bool FARK>
 __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, StripRec xr, int q, int s, int round) {
   using SM = MfeStripSmem<NT>;
   constexpr int NW = SM::NW, RS = SM::RS, P = SM::P, NFIN = SM::NFIN, NSVC = SM::NSVC, NG = SM::NG;
@@ -224,7 +229,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   }
   for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
   for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
-  if (tid == 0) { sm.flag = 0; sm.sync_fail[0] = 0; sm.sync_fail[1] = 0; sm.far_cnt[0] = 0; sm.far_cnt[1] = 0; }
+  if (tid == 0) { sm.flag = 0; sm.sync_fail[0] = 0; sm.sync_fail[1] = 0; }
   __syncthreads();
   // local sequence and pairing codes (4 = may not pair: positions paired in an earlier round, and both ends)
   const char* seq = A.seqs + so;
@@ -344,6 +349,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 
   const auto rsF = __builtin_amdgcn_make_buffer_rsrc((void*)FML, (short)0, (int)(tab * 4), 0x00020000);
   const auto rsE = __builtin_amdgcn_make_buffer_rsrc((void*)EXT, (short)0, (int)(tab * 4), 0x00020000);
+  constexpr bool fark = FARK;                           // blocked multiloop splits (see MKT_L): a kernel of its own, so that the plain items keep their registers
   const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
 
   // floating work items of diagonal d: multiloop splits from L2 (64 cells x 4 split-point groups per item, four adjacent cells
@@ -352,21 +358,17 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
     const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
     const int tmax = d - TURN - 2;
-    // near split points: everything while no tile can have far blocks yet (d < 57), else the two ends of the range (the far
-    // blocks start <= 63 and end <= 80 split points from the ends; what a far block covers is masked per cell)
-#if MSTRIP_FARK
-    const bool two = MSTRIP_FARK && tmax > 63 + 16 && d - 80 > 64;
-    const int nterm = two ? 60 + (tmax - (d - 80) + 1) : tmax - TURN;
-    const int kssh = nterm > 96 ? 3 : nterm > 48 ? 2 : nterm > 24 ? 1 : 0;
-    const int KS = 1 << kssh, KG = 4 << kssh;
-#else
-    const int kssh = d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0;
+    // blocked form (fark): the near split points of the diagonal -- tt = m - 1 - i over [TURN+1, 28+MKT_L] and [d-29-MKT_L,
+    // d-TURN-2], every cell masks what belongs to its tile's far range; one range while cells without a far range exist on the
+    // diagonal (d < 16 MKT_BMIN) or the two meet
+    const bool whole = !fark || d < 16 * MKT_BMIN || 28 + MKT_L + 1 >= d - 29 - MKT_L;
+    const int n1 = whole ? tmax - TURN : 28 + MKT_L - TURN, s2 = d - 29 - MKT_L;
+    const int nterm = whole ? n1 : n1 + tmax - s2 + 1;
+    const int kssh = fark ? (nterm > 96 ? 3 : nterm > 48 ? 2 : nterm > 24 ? 1 : 0) : (d > 96 ? 3 : d > 48 ? 2 : d > 24 ? 1 : 0);
     const int KS = 1 << kssh, KG = 4 << kssh;
     const int astep = 4 * KG * ld, cstep = 4 * KG * (ld - 1);
-#endif
     const int nK = (MSTRIP_SKIP & 1) ? 0 : ((ncell + 63) >> 6) << kssh, nE = (MSTRIP_SKIP & 2) ? 0 : (pcnt + 3) >> 2;
-    const int nF = (MSTRIP_FARK && !(MSTRIP_SKIP & 16)) ? __builtin_amdgcn_readfirstlane(sm.far_cnt[par]) : 0;
-    const int nKF = nK + nF;
+    const int nKF = nK;
     const int nItems = __builtin_amdgcn_readfirstlane(nKF + nE);
     auto pop = [&]() -> int {
       if (decltype(with_k)::value) {
@@ -376,27 +378,30 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       return nKF + queue_pop(&sm.qe[par], lane);
     };
     for (int it = pop(); it < nItems; it = pop()) {
-      if (decltype(with_k)::value && it >= nF && it < nKF) {
-#if MSTRIP_FARK
-        const int itk = it - nF;
-        const int g = (itk & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
-        int i = ((itk >> kssh) << 6) + 4 * cl + 1;
+      if (decltype(with_k)::value && it < nKF) {
+        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
+        int i = ((it >> kssh) << 6) + 4 * cl + 1;
         const bool act = i <= ncell;
         i = act ? i : 1;
         const int ig = i + c0 - 1;
-        // per cell: split points tt <= lb or tt >= rb are near (all of them when the cell's tile has no far blocks)
-        int lb[4], rb[4];
+        int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
+       if (fark) {
+        // the lane's four cells (i + x, i + x + d): same tile row (i - 1 is a multiple of 4), maybe different tile columns; split
+        // points tt <= lb or tt >= rb are near (all of them when the cell's tile has no far range)
+        int lb[4], rb[4], fv[4];
+        const int t16 = (i - 1) & ~15;
+        const bool head = (it & (KS - 1)) == 0 && lane < 16;               // these lanes fold the tile's far minimum in
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-          int bk_lo, bk_hi;
-          const bool hf = MSTRIP_FARK && far_blocks(c0, c1, (i - 1) >> 4, (ig + x + d) >> 4, bk_lo, bk_hi);
-          lb[x] = hf ? 16 * bk_lo - (ig + x) - 2 : 0x3fffffff;
-          rb[x] = hf ? 16 * bk_hi + 15 - (ig + x) : 0x3fffffff;
+          const int b16 = (i + x + d - 1) & ~15;
+          const bool hf = b16 - t16 >= 16 * MKT_BMIN;
+          lb[x] = hf ? t16 + 29 + MKT_L - (i + x) : 0x3fffffff;
+          rb[x] = hf ? b16 - 13 - MKT_L - (i + x) : 0x3fffffff;
+          fv[x] = (head && hf) ? sm.dfar[t16 >> 4][(b16 >> 4) & 1][((i + x - 1) & 15) * 16 + ((i + x + d - 1) & 15)] : INF;
         }
-        int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
-        // the near split points as ONE index range v = 0 .. nv-1 (v < n1: tt = 4 + v; else tt = d - 80 + v - n1), dealt to the
+        // the near split points as ONE index range v = 0 .. nv-1 (v < n1: tt = TURN + 1 + v; else tt = s2 + v - n1), dealt to the
         // lanes' groups by v: four of them per trip, eight loads in flight
-        const int n1 = two ? 60 : tmax - TURN, r0 = two ? d - 80 : 0, nv = two ? 60 + (tmax - (d - 80) + 1) : n1;
+        const int r0 = s2, nv = nterm;
         auto tt_of = [&](const int v) { return v < n1 ? TURN + 1 + v : r0 + (v - n1); };
 #define NEARV(x, tq) ((tq) <= lb[x] || (tq) >= rb[x])
         for (int v = g; v < nv; v += 4 * KG) {
@@ -418,16 +423,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           }
         }
 #undef NEARV
-#else
-        const int tmax_ = tmax;
-        const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
-        int i = ((it >> kssh) << 6) + 4 * cl + 1;
-        const bool act = i <= ncell;
-        i = act ? i : 1;
-        const int ig = i + c0 - 1;
-        int m0 = INF, m1 = INF, m2 = INF, m3 = INF;
+        m0 = min(m0, fv[0]); m1 = min(m1, fv[1]); m2 = min(m2, fv[2]); m3 = min(m3, fv[3]);
+       } else {
         int tt = TURN + 1 + g;
-        const int tmax = tmax_;
         int vA = (tt * ld + ig) * 4;                               // fML[i .. i+3, . + tt]
         int vC = ((d - tt - 1) * ld + ig + tt + 1) * 4;            // fML[i+tt+1 .. , j ..]
         // split points in batches of KU (16 loads in flight), then 4, then the last <= 3 at once (masked): every batch is ONE
@@ -453,7 +451,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
         for (; tt + (KU - 1) * KG <= tmax;) batch(std::integral_constant<int, KU>{}, KU);
         for (; tt + 3 * KG <= tmax;) batch(std::integral_constant<int, 4>{}, 4);
         if (tt <= tmax) batch(std::integral_constant<int, 3>{}, (tmax - tt) / KG + 1);
-#endif
+       }
         // the four 16-lane rows hold different split points of the same cells
         m0 = min(m0, __shfl_xor(m0, 16)); m1 = min(m1, __shfl_xor(m1, 16)); m2 = min(m2, __shfl_xor(m2, 16)); m3 = min(m3, __shfl_xor(m3, 16));
         m0 = min(m0, __shfl_xor(m0, 32)); m1 = min(m1, __shfl_xor(m1, 32)); m2 = min(m2, __shfl_xor(m2, 32)); m3 = min(m3, __shfl_xor(m3, 32));
@@ -463,55 +461,6 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           if (i + 2 <= ncell && m2 < HALF) atomicMin(&sm.accK[par][(i + 2 + sh) & (P - 1)], m2);
           if (i + 3 <= ncell && m3 < HALF) atomicMin(&sm.accK[par][(i + 3 + sh) & (P - 1)], m3);
         }
-      } else if (MSTRIP_FARK && decltype(with_k)::value && it < nF) {
-        // ---- far item (first in the queue: its loads come from beyond the L2): nb tile products of tile (t, bj), k-blocks b0 ..: lane (r, q) = row r of the tile, columns 4q .. 4q+3
-        const int e = sm.far_tab[par][it];
-        const int t = e & 15, bj = (e >> 4) & 255, b0 = (e >> 12) & 255, nb = (e >> 20) & 15;
-        const int r = lane & 15, qq = lane >> 4;
-        const int imin = c0 + 16 * t, jmin = 16 * bj;
-        const int w = __builtin_amdgcn_readfirstlane(wave_id());
-        int* As = sm.fstage[w];
-        int* Cs = As + 16 * 17;
-        int acc0 = INF, acc1 = INF, acc2 = INF, acc3 = INF;
-        // every operand of the item's (up to FAR_CH) products is requested first: one trip beyond the L2 for all of them
-        int av[FAR_CH][4], cv[FAR_CH][4];
-#pragma unroll
-        for (int b = 0; b < FAR_CH; b++) {
-          const int kmin = 16 * (b0 + b);
-          // A[r][c] = F[imin + r, kmin + c - 1] (row = diagonal kmin + c - 1 - i of the strip's own cells);
-          // C[r][c] = F[kmin + r, jmin + c] (any strip above: sc1)
-#pragma unroll
-          for (int x = 0; x < 4; x++) {
-            const int c = 4 * qq + x;
-            const int ia = imin + r, ka = kmin + c;
-            const int kc = kmin + r, jc = jmin + c;
-            av[b][x] = INF; cv[b][x] = INF;
-            if (b < nb) {
-              if (ia <= c1) av[b][x] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, ((ka - 1 - ia) * ld + ia) * 4, 0, 0);
-              if (jc <= n) cv[b][x] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, ((jc - kc) * ld + kc) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
-            }
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < FAR_CH; b++) {
-          if (b < nb) {
-            wave_lds_sync();                       // (the previous product's reads are done)
-#pragma unroll
-            for (int x = 0; x < 4; x++) { As[r * 17 + 4 * qq + x] = av[b][x]; Cs[r * 16 + 4 * qq + x] = cv[b][x]; }
-            wave_lds_sync();
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-              const int a = As[r * 17 + kk];
-              const int* cr = Cs + kk * 16 + 4 * qq;
-              acc0 = min(acc0, a + cr[0]); acc1 = min(acc1, a + cr[1]); acc2 = min(acc2, a + cr[2]); acc3 = min(acc3, a + cr[3]);
-            }
-          }
-        }
-        int* dst = sm.dfar[t][bj & 3] + r * 16 + 4 * qq;
-        if (acc0 < HALF) atomicMin(dst, acc0);
-        if (acc1 < HALF) atomicMin(dst + 1, acc1);
-        if (acc2 < HALF) atomicMin(dst + 2, acc2);
-        if (acc3 < HALF) atomicMin(dst + 3, acc3);
       } else {
         mfe_e_item_rows(sm, it - nKF, d, par, pcnt, sh, lane, TermAU, e_bulge1, e_int23, P - 1);
       }
@@ -562,38 +511,6 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       sa_f = __builtin_amdgcn_readfirstlane(ld_agent(up_flag));
     }
     if (k + 1 < n_loc) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
-    if (MSTRIP_FARK) {
-      // far items of step k+1: the tiles (t, bj) whose first cell is due far_lat(t) diagonals later; their LDS slots start at INF
-      const int dn = k + 1;
-      int cnt = 0;
-      if (dn < n_loc) {
-        const int ntile = (wid + 15) >> 4;
-        for (int t = 0; t < ntile; t++) {
-          const int imax = min(c0 + 16 * t + 15, c1);
-          // a tile's products are dealt to two steps: the lower half of its k-blocks far_lat(t) diagonals before its first
-          // cell is due (the slot is set to INF one step earlier, i.e. here), the upper half one step later
-#pragma unroll
-          for (int half = 0; half < 2; half++) {
-            const int jmin = dn - half + far_lat(t) + imax;
-            int bk_lo, bk_hi;
-            if ((jmin & 15) == 0 && jmin <= n && far_blocks(c0, c1, t, jmin >> 4, bk_lo, bk_hi)) {
-              const int bj = jmin >> 4;
-              if (half == 0) {
-                int* slot = sm.dfar[t][bj & 3];
-                slot[lane] = INF; slot[lane + 64] = INF; slot[lane + 128] = INF; slot[lane + 192] = INF;
-              }
-              const int mid = bk_lo + ((bk_hi - bk_lo + 1) >> 1);           // lower half: bk_lo .. mid-1, upper: mid .. bk_hi
-              const int f0 = half ? mid : bk_lo, f1 = half ? bk_hi : mid - 1;
-              for (int b0 = f0; b0 <= f1 && cnt < FAR_TAB; b0 += FAR_CH) {
-                if (lane == 0) sm.far_tab[dn & 1][cnt] = t | (bj << 4) | (b0 << 12) | (min(FAR_CH, f1 - b0 + 1) << 20);
-                cnt++;
-              }
-            }
-          }
-        }
-      }
-      if (lane == 0) sm.far_cnt[dn & 1] = cnt;
-    }
   };
   // B: pairable list of diagonal k+1 (entries beyond the count are never read, so the rows do not wait for it); exterior
   //    column j = k-3 (last strip).  Both requested one step ahead: lp_* / fx_*.
@@ -650,6 +567,73 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     sb_request(k + 1);              // column k-2: its cells (diagonals <= k-3) were stored in step k-2 and drained by its barrier
   };
 
+  // ---- tile products of the blocked form (see MKT_L above and fold_pf_strip.hpp).  Tile waves: the floating and the service waves
+  // (one tile row each), or the finalize waves of a workgroup that has neither.  At step k the tiles of block distance
+  // B = (k + 15 + MKT_W) >> 4 are in step g = (k + 15 + MKT_W) & 15 of their window (g < MKT_W).
+  constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * NG;
+  constexpr int NTW = NFLOAT > 0 ? NFLOAT + NSVC : NFIN;
+  constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
+  const int tf = NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * NG : NFLOAT + wave - NFIN) : wave;
+  int tacc[TOWN][4];
+#pragma unroll
+  for (int o = 0; o < TOWN; o++) { tacc[o][0] = INF; tacc[o][1] = INF; tacc[o][2] = INF; tacc[o][3] = INF; }
+  auto tile_job = [&](const int k) {
+    const int xk = k + 15 + MKT_W, B = xk >> 4, g = xk & 15;
+    if (!fark || (MSTRIP_SKIP & 16) || g >= MKT_W || B < MKT_BMIN) return;
+    const int h = lane >> 4, x = lane & 15;
+#pragma unroll
+    for (int o = 0; o < TOWN; o++) {
+      const int t = tf + NTW * o, bj = t + B;
+      if (16 * t >= wid || 16 * bj + 1 > n_loc) continue;                   // (wave-uniform) no such tile in this strip / triangle
+      const int m_lo = 16 * t + 31 + MKT_L, m_hi = 16 * bj - 13 - MKT_L;
+      const int nch = (m_hi - m_lo + 4) >> 2, nl = (nch + 1) >> 1, nh = nch >> 1;
+      const int cl = (nl + MKT_W - 1) / MKT_W, ch = (nh + MKT_W - 1) / MKT_W, e = MKT_W - 1 - g;
+      const int lo0 = e * cl, nlo = max(0, min(nl, lo0 + cl) - lo0), hi0 = e * ch, nhi = max(0, min(nh, hi0 + ch) - hi0);
+      const int ncs = nlo + nhi;                                              // chunks of this step: low side first
+      // lane (h, x) loads fML(i_min + h + 4 (x >> 2), m - 1) for m = m0 + (x & 3) and fML(m0 + h, j_min + x); rows / columns
+      // beyond the strip or the sequence repeat the last one (their minima are never read)
+      const int il = min(16 * t + 1 + h + 4 * (x >> 2), wid), jl = min(16 * bj + 1 + x, n_loc);
+      const int oA = ((-1 - il) * ld + c0 - 1 + il) * 4, oB = (jl * ld + c0 - 1) * 4;       // + m * (ld * 4)  |  - m * (ld - 1) * 4
+      int acc0 = tacc[o][0], acc1 = tacc[o][1], acc2 = tacc[o][2], acc3 = tacc[o][3];
+      if (g == 0) { acc0 = INF; acc1 = INF; acc2 = INF; acc3 = INF; }
+      constexpr int DEPTH = 8;                                                // chunks in flight (16 loads)
+      for (int c = 0; c < ncs; c += DEPTH) {
+        int av[DEPTH], bv[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; u++) {
+          av[u] = INF; bv[u] = INF;
+          if (c + u < ncs) {
+            const int cid = c + u < nlo ? lo0 + c + u : nch - 1 - (hi0 + c + u - nlo);
+            const int m0 = m_lo + 4 * cid;
+            const int ma = m0 + (x & 3), mb = m0 + h;
+            av[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, oA + min(ma, m_hi) * (ld * 4), 0, 0);
+            bv[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, oB - min(mb, m_hi) * ((ld - 1) * 4), 0, (STRIP_DIAG & 2) ? 0 : 16);
+            if (ma > m_hi) av[u] = INF;
+            if (mb > m_hi) bv[u] = INF;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; u++) {
+          if (c + u < ncs) {
+            // second operands of the lane's column for the chunk's four split points; first operands by row broadcast
+            const int b0 = lane_fetch_i32(bv[u], x), b1 = lane_fetch_i32(bv[u], 16 + x), b2 = lane_fetch_i32(bv[u], 32 + x),
+                      b3 = lane_fetch_i32(bv[u], 48 + x);
+            const int a = av[u];
+            acc0 = min(acc0, min(min(row_bcast_i32<0>(a) + b0, row_bcast_i32<1>(a) + b1), min(row_bcast_i32<2>(a) + b2, row_bcast_i32<3>(a) + b3)));
+            acc1 = min(acc1, min(min(row_bcast_i32<4>(a) + b0, row_bcast_i32<5>(a) + b1), min(row_bcast_i32<6>(a) + b2, row_bcast_i32<7>(a) + b3)));
+            acc2 = min(acc2, min(min(row_bcast_i32<8>(a) + b0, row_bcast_i32<9>(a) + b1), min(row_bcast_i32<10>(a) + b2, row_bcast_i32<11>(a) + b3)));
+            acc3 = min(acc3, min(min(row_bcast_i32<12>(a) + b0, row_bcast_i32<13>(a) + b1), min(row_bcast_i32<14>(a) + b2, row_bcast_i32<15>(a) + b3)));
+          }
+        }
+      }
+      tacc[o][0] = acc0; tacc[o][1] = acc1; tacc[o][2] = acc2; tacc[o][3] = acc3;
+      if (g == MKT_W - 1) {                    // accumulator rr of lane (h, x): cell (row h + 4 rr, column x) of the tile
+        int* slot = sm.dfar[t][bj & 1] + h * 16 + x;
+        slot[0] = acc0; slot[64] = acc1; slot[128] = acc2; slot[192] = acc3;
+      }
+    }
+  };
+
   bool failed = false;
 #ifdef MSTRIP_STAMPS
   long long st_acc[4] = {0, 0, 0, 0}, st_last = clock64();
@@ -702,11 +686,6 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           }
           if (c < INF) f = min(f, c + MLintern + tau + sm.mmM[t * 16 + sm.S[i - 1] * 4 + sm.S[j + 1]]);
           int aKf = aK;
-          if (MSTRIP_FARK) {
-            int bk_lo, bk_hi;
-            const int tI = (i - 1) >> 4;
-            if (far_blocks(c0, c1, tI, jg >> 4, bk_lo, bk_hi)) aKf = min(aKf, sm.dfar[tI][(jg >> 4) & 3][((i - 1) & 15) * 16 + (jg & 15)]);
-          }
           const int dec = aKf >= HALF ? INF : aKf;
           sm.dml[(d & 3) * RS + i] = dec;
           const int fv = min(f, dec);
@@ -722,6 +701,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
       MST(0);
+      if (NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       MST(1);
       STRIP_BARRIER();
@@ -733,16 +713,16 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (wave == w_svcA) service_a(k); else service_b(k);
       MST(0);
-      if (k < n_loc) run_items(k, std::true_type{});
+      if (k < n_loc) { tile_job(k); run_items(k, std::true_type{}); }
       MST(1);
       STRIP_BARRIER();
       MST(2);
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }
   } else if (!pinned) {
-    // ================= floating waves: items only
+    // ================= floating waves: tile products and items
     for (int k = TURN + 1; k <= n_loc; k++) {
-      if (k < n_loc) run_items(k, std::true_type{});
+      if (k < n_loc) { tile_job(k); run_items(k, std::true_type{}); }
       MST(1);
       STRIP_BARRIER();
       MST(2);
@@ -810,14 +790,14 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 #else
 #define MSTRIP_ATTR
 #endif
-template <int NT>
+template <int NT, bool FARK>
 __global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
   __shared__ MfeStripSmem<NT> sm;
   const int b = blockIdx.x, per = 8 * (lk.S + lk.pad);
   const int grp = b / per, x = b - grp * per;
   const int q = grp * 8 + (x & 7), s = x >> 3;
   if (q >= lk.nseq || s >= lk.S) return;          // (padding blocks: see STRIP_PAD)
-  mfe_strip_body<NT>(sm, A, lk, xr, q, s, round);
+  mfe_strip_body<NT, FARK>(sm, A, lk, xr, q, s, round);
 }
 
 // traceback of one round, one wave per sequence, on the tables the strips of that round left in HBM (a launch of its own: the

@@ -24,7 +24,7 @@ def build(flags=(), tag=""):
     L.emu_pf.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_mfe_dual.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, vp, vp, vp]
     L.emu_pf_strip.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, vp, vp]
-    L.emu_mfe_strip.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, ci, vp, vp, vp]
+    L.emu_mfe_strip.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci, ci, vp, vp, vp, ci]
     L.emu_eval.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, vp, vp]
     L.emu_ragged.argtypes = [vp, ci, ci, ci, vp, vp, C.c_char_p, ci, vp, vp, vp, vp]
     L.emu_cofold.argtypes = [vp, ci, ci, ci, ci, C.c_char_p, ci, vp, vp, vp, vp, vp, vp]
@@ -75,14 +75,14 @@ class Emu:
         assert rc == 0
         return E, st
 
-    def mfe_strip(self, seqs, S, pk_rounds=0, nt=256, calls=1):
+    def mfe_strip(self, seqs, S, pk_rounds=0, nt=256, calls=1, fark=0):
         """MFE fold by S strips of columns per sequence (+ the traceback launch per round); returns (Emfe, structures, status)"""
         R, L = len(seqs), len(seqs[0])
         E = np.zeros(R, dtype=np.int32)
         ss = np.zeros((R, L), dtype=np.uint8)
         st = np.zeros(R, dtype=np.int32)
         rc = self.L.emu_mfe_strip(self.blob.ctypes.data, self.blob.size, R, L, "".join(seqs).encode(), pk_rounds, nt, S, calls,
-                                  E.ctypes.data, ss.ctypes.data, st.ctypes.data)
+                                  E.ctypes.data, ss.ctypes.data, st.ctypes.data, int(fark))
         assert rc == 0
         return E, [bytes(r).decode() for r in ss], st
 

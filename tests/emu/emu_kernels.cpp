@@ -75,7 +75,7 @@ static void run_pf_strip(const PfArgs& a, int R, int S, int calls) {
 
 // strip kernel of the MFE fold: per pseudoknot round the S strips of a sequence side by side, then the traceback "launch"
 template <int NT>
-static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls) {
+static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls, int fark) {
   std::vector<int> flags((size_t)R * STRIP_MAXS * 32, 0);
   StripRec xr;
   xr.stride = (long long)S * a.ld * MSTRIP_REC;
@@ -90,9 +90,13 @@ static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls) {
       epoch++;
       for (int r = 0; r < R; r++) {
         StripLink lk;
-        lk.flags = flags.data(); lk.base = epoch << 12; lk.nseq = R; lk.S = S;
+        lk.flags = flags.data(); lk.base = epoch << 12; lk.nseq = R; lk.S = S; lk.fark = fark;
         std::vector<std::function<void()>> fns;
-        for (int s = 0; s < S; s++) fns.push_back([&, r, s, lk, round]() { mfe_strip_body<NT>(*sms[s], a, lk, xr, r, s, round); });
+        for (int s = 0; s < S; s++)
+          fns.push_back([&, r, s, lk, round]() {
+            if (lk.fark) mfe_strip_body<NT, true>(*sms[s], a, lk, xr, r, s, round);
+            else mfe_strip_body<NT, false>(*sms[s], a, lk, xr, r, s, round);
+          });
         emu_launch_many(r * S, NT, fns);
       }
       for (int r = 0; r < R; r++) emu_launch(r, 64, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round, 0); });
@@ -104,7 +108,7 @@ static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls) {
 extern "C" {
 
 int emu_mfe_strip(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int pk_rounds, int nt, int S, int calls,
-                  int32_t* Emfe, char* ss, int32_t* status) {
+                  int32_t* Emfe, char* ss, int32_t* status, int fark) {
   Ctx* c = make_ctx(blob, n_int32, L);
   if (!c->ok) { delete c; return -1; }
   const int ld = L + 2;
@@ -114,8 +118,8 @@ int emu_mfe_strip(const int32_t* blob, int n_int32, int R, int L, const char* se
   a.seqs = seqs; a.L = L; a.ld = ld; a.pk_rounds = pk_rounds;
   a.ws = ws.data(); a.ws_stride = (long long)5 * ld * ld;
   a.Emfe = Emfe; a.ss = ss; a.status = status;
-  if (nt == 256) run_mfe_strip<256>(a, R, S, calls);
-  else run_mfe_strip<1024>(a, R, S, calls);
+  if (nt == 256) run_mfe_strip<256>(a, R, S, calls, fark);
+  else run_mfe_strip<1024>(a, R, S, calls, fark);
   delete c;
   return 0;
 }

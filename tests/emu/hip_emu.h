@@ -78,6 +78,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   if (ctrl == 0xE4) return src;        // identity quad_perm (as_vector()): no lane talks to another, no rendezvous needed
   int from = -1;
   if (ctrl >= 0x111 && ctrl <= 0x11F) { const int nsh = ctrl - 0x110; if ((L & 15) >= nsh) from = L - nsh; }
+  else if (ctrl >= 0x150 && ctrl <= 0x15F) from = r * 16 + (ctrl - 0x150);     // row_newbcast: lane n of the own row
   else if (ctrl == 0x142) { if (r > 0) from = r * 16 - 1; }
   else if (ctrl == 0x143) { if (r >= 2) from = 31; }
   const int got = emu_exchange(src, from < 0 ? L : from);       // every lane takes part in the rendezvous

@@ -695,6 +695,38 @@ def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
         eng400.score_batch(["ACGU" * 60 + "N" + "ACGU" * 2], E.NEED_MFE | E.NEED_PF)
 
 
+def test_blocked_mfe_strips_equal_plain_strips(eng400, oracle):
+    """From six strips on (n > 600) the MFE strips fold their multiloop splits in blocked form (tile products of the far split
+    points, fold_mfe_strip.hpp MKT_L).  Forced here for two to four strips ("mfe_fark_min_strips" = 2), with pseudoknot rounds and
+    a batch above one workgroup per CU: structures and energies must equal the plain strips' and the oracle's; and 700 nt through
+    the default switch against the general kernel."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(2410)
+    for L, R, pk in ((205, 6, True), (333, 40, True), (400, 96, False)):
+        seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
+        flags = E.NEED_MFE | (E.NEED_PK if pk else 0)
+        a = eng400.score_batch(seqs, flags)
+        try:
+            eng400.set_option("mfe_fark_min_strips", 2)
+            b = eng400.score_batch(seqs, flags)
+            c = eng400.score_batch(seqs, flags)
+        finally:
+            eng400.set_option("mfe_fark_min_strips", 6)
+        assert a["mfe_ss"] == b["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all() and (b["Emfe"] == c["Emfe"]).all()
+        for k in (0, R - 1):
+            ss, e = oracle.mfe(seqs[k])
+            if pk:
+                ss = oracle.pk_struct(seqs[k], ss)
+            assert b["mfe_ss"][k] == ss and int(b["Emfe"][k]) == e
+    eng = E.Engine(max_R=3, max_L=700, device=0)
+    seqs = [_rand(rng, 700) for _ in range(3)]
+    a = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PK)
+    eng.set_option("strips", 0)
+    b = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PK)
+    eng.close()
+    assert a["mfe_ss"] == b["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all()
+
+
 def test_lost_strip_falls_back_to_one_workgroup_per_fold(eng400, oracle):
     """HIP promises no dispatch order, so a fold by several workgroups may lose a partner (bounded wait -> ST_SYNC).  That must
     not fail the call: the engine redoes it with one workgroup per fold.  Injected here ("strip_fault": the top strip of every

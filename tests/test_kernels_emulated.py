@@ -267,17 +267,18 @@ def test_mfe_strip_kernel(emu, oracle):
     assert st[0] == 1 and ss[0] == "." * 100
 
 
-def test_mfe_strip_kernel_blocked_splits(blob, oracle):
-    """The blocked form of the multiloop splits in fold_mfe_strip.hpp (-DMSTRIP_FARK=1: 16 x 16 tiles of cells, far k-blocks as
-    tile products through LDS, near split points masked per cell; off by default: correct but not yet faster):
-    energies and structures must equal the oracle's.  124 nt in three strips: far blocks exist from diagonal ~57 on."""
-    emu_f = Emu(blob, flags=("-DMSTRIP_FARK=1",), tag="_fark")
+def test_mfe_strip_kernel_blocked_splits(emu, oracle):
+    """The blocked form of the multiloop splits in fold_mfe_strip.hpp (StripLink::fark; the engine switches it on for long folds):
+    16 x 16 tiles of cells, the far split points as (min,+) tile products by DPP row broadcasts and lane fetches spread over the
+    16 steps before the tile is due, near split points masked per cell.  150 nt in three strips of 50 columns, with a pseudoknot
+    round: energies and structures must equal the oracle's."""
     rng = np.random.default_rng(4112)
-    seqs = [_rand(rng, 124, "GGCCAU")]
-    E, ss, st = emu_f.mfe_strip(seqs, 3, pk_rounds=0, nt=256, calls=1)
+    seqs = [_rand(rng, 150, "GGCCAU")]
+    E, ss, st = emu.mfe_strip(seqs, 3, pk_rounds=1, nt=256, calls=1, fark=1)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
-        assert (ss[k], int(E[k])) == oracle.mfe(s), s
+        ref, e = oracle.mfe(s)
+        assert (ss[k], int(E[k])) == (oracle.pk_struct(s, ref), e), s
 
 
 @pytest.mark.parametrize("L,nt", [(30, -257), (64, -257), (96, -1025)])
