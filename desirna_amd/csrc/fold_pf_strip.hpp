@@ -52,6 +52,17 @@ namespace drna {
 #ifndef PSTRIP_SKIP
 #define PSTRIP_SKIP 0        // diagnostic builds only (timing; results wrong): 1 no multiloop items, 2 no bulge / 1xn items, 4 no small shapes, 8 no towers, 16 no tile products
 #endif
+#ifndef DRNA_PKT_OVERLAP
+#define DRNA_PKT_OVERLAP 0
+#endif
+constexpr bool PKT_OVERLAP = DRNA_PKT_OVERLAP != 0;     // 1: floating tile waves run the first item of the step between the tile loads and the products (measured: 36 spilled VGPRs, 1.72 vs 1.59 ms)
+#ifndef DRNA_PKT_TOWER
+#define DRNA_PKT_TOWER 0
+#endif
+constexpr int PKT_TOWER = DRNA_PKT_TOWER;               // 1: the tower (+ service) waves take the tile rows, their tower step under the loads (measured: 100 spilled VGPRs, 2.5 vs 1.57 ms at 400 nt; 1.9 with 3 chunks in flight)
+#ifndef DRNA_PKT_DEPTH
+#define DRNA_PKT_DEPTH 8
+#endif
 #ifndef DRNA_PKT_NB
 #define DRNA_PKT_NB 4
 #endif
@@ -311,7 +322,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
 
   // floating work items of diagonal d (see pf_lds_kernel): multiloop sums from L2 (the qm1 operand may be another strip's: sc1),
   // bulge / 1xn shapes, fixed small shapes.  Output slots are physical tower lanes (i_loc + d/2) mod P.
-  auto run_items = [&](const int d, auto with_k) {
+  auto run_items = [&](const int d, auto with_k, int budget = 1 << 30) {
     const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
     const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
     // near split points of the diagonal (tile geometry: see PKT_L): tt = m - 1 - i runs over [TURN+1, 28+PKT_L] and
@@ -338,7 +349,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
       }
       return nK + queue_pop(&sm.qe[par], lane);
     };
-    for (int it = pop(); it < nItems; it = pop()) {
+    for (int it = budget > 0 ? pop() : nItems; it < nItems; it = --budget > 0 ? pop() : nItems) {
       if (decltype(with_k)::value && it < nK) {
         const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
         int i = ((it >> kssh) << 5) + 2 * cl + 1;
@@ -547,63 +558,95 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     }
   };
 
-  // ---- tile products (see PKT_L above).  Tile waves: the floating waves, or the finalize waves of a workgroup that has none;
-  // tile wave f owns the tile rows f, f + NTW, ...  At step k the tiles of block distance B = (k + 15 + PKT_W) >> 4 are in step
+  // ---- tile products (see PKT_L above).  Tile waves (PKT_TOWER): the tower waves and the service waves, one tile row each --
+  // a tower wave requests its chunks' operands, runs its tower step (LDS work) under their round trip and multiplies afterwards
+  // (tile_issue / tile_finish); else the floating (+ service) waves; the finalize waves of a workgroup that has neither.  Tile wave
+  // f owns the tile rows f, f + NTW, ...  At step k the tiles of block distance B = (k + 15 + PKT_W) >> 4 are in step
   // g = (k + 15 + PKT_W) & 15 of their window (g < PKT_W; k = d_min - PKT_W + g): operands on diagonals <= d_min - PKT_L <= k - 2.
   constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * PNG;
-  constexpr int NTW = NFLOAT > 0 ? NFLOAT + (PKT_SVC ? NSVC : 0) : NFIN;    // (with the service waves: one tile row per tile wave)
+  constexpr bool TILE_ON_TOWERS = PKT_TOWER != 0;
+  constexpr int NTW = TILE_ON_TOWERS ? NFIN * PNG + NSVC : NFLOAT > 0 ? NFLOAT + (PKT_SVC ? NSVC : 0) : NFIN;
   constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
-  const int tf = NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * PNG : NFLOAT + wave - NFIN) : wave;
+  const int tf = TILE_ON_TOWERS ? (aw >= 0 ? aw : NFIN * PNG + wave - NFIN)
+                                : NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * PNG : NFLOAT + wave - NFIN) : wave;
   f64x4 tacc[TOWN];
 #pragma unroll
   for (int o = 0; o < TOWN; o++) tacc[o] = f64x4{0.0, 0.0, 0.0, 0.0};
-  constexpr int PKT_DEPTH = 8;              // chunks in flight (16 loads)
-  auto tile_job = [&](const int k) {
-    const int x = k + 15 + PKT_W, B = x >> 4, g = x & 15;
-    if (!PSTRIP_FARK || (PSTRIP_SKIP & 16) || g >= PKT_W || B < PKT_BMIN) return;
-    const int r = lane & 15, kk = lane >> 4;
+  constexpr int PKT_DEPTH = DRNA_PKT_DEPTH;              // chunks in flight (two loads each)
+  double tq_a[TOWN][PKT_DEPTH], tq_b[TOWN][PKT_DEPTH];   // operands requested by tile_issue
+  struct TileStep { int t, bj, m_lo, m_hi, nch, lo0, nlo, hi0, ncs, oA, oB; bool on; };
+  auto tile_step = [&](const int k, const int o, int& g) -> TileStep {
+    TileStep q;
+    const int x = k + 15 + PKT_W, B = x >> 4;
+    g = x & 15;
+    q.t = tf + NTW * o; q.bj = q.t + B;
+    q.on = PSTRIP_FARK && !(PSTRIP_SKIP & 16) && g < PKT_W && B >= PKT_BMIN && 16 * q.t < wid && 16 * q.bj + 1 <= n_loc;   // (wave-uniform)
+    q.m_lo = 16 * q.t + 31 + PKT_L; q.m_hi = 16 * q.bj - 13 - PKT_L;
+    q.nch = (q.m_hi - q.m_lo + 4) >> 2;
+    const int nl = (q.nch + 1) >> 1, nh = q.nch >> 1;
+    const int cl = (nl + PKT_W - 1) / PKT_W, ch = (nh + PKT_W - 1) / PKT_W, e = PKT_W - 1 - g;
+    q.lo0 = e * cl; q.nlo = max(0, min(nl, q.lo0 + cl) - q.lo0); q.hi0 = e * ch;
+    const int nhi = max(0, min(nh, q.hi0 + ch) - q.hi0);
+    q.ncs = q.nlo + nhi;                                                      // chunks of this step: low side first
+    // rows / columns beyond the strip or the sequence repeat the last one: their sums are never stored
+    const int r = lane & 15;
+    const int il = min(16 * q.t + 1 + r, wid), jl = min(16 * q.bj + 1 + r, n_loc);
+    q.oA = ((-1 - il) * ld + c0 - 1 + il) * 8; q.oB = (int)tab * 8 + (jl * ld + c0 - 1) * 8;     // + m * (ld * 8)  |  - m * (ld - 1) * 8
+    return q;
+  };
+  auto tile_load = [&](const TileStep& q, const int c, double& a, double& b) {
+    const int cid = c < q.nlo ? q.lo0 + c : q.nch - 1 - (q.hi0 + c - q.nlo);
+    const int m = q.m_lo + 4 * cid + (lane >> 4), mc = min(m, q.m_hi);
+    a = buf_load_f64(rsQ, q.oA + mc * (ld * 8), 0);                 // QM(i, m - 1): own columns
+    b = buf_load_f64_aux(rsQ, q.oB - mc * ((ld - 1) * 8), 0);       // QM1(m, j): maybe another strip's
+    if (m > q.m_hi) a = 0.0;
+  };
+  auto tile_issue = [&](const int k) {
 #pragma unroll
     for (int o = 0; o < TOWN; o++) {
-      const int t = tf + NTW * o, bj = t + B;
-      if (16 * t >= wid || 16 * bj + 1 > n_loc) continue;                   // (wave-uniform) no such tile in this strip / triangle
-      const int m_lo = 16 * t + 31 + PKT_L, m_hi = 16 * bj - 13 - PKT_L;
-      const int nch = (m_hi - m_lo + 4) >> 2, nl = (nch + 1) >> 1, nh = nch >> 1;
-      const int cl = (nl + PKT_W - 1) / PKT_W, ch = (nh + PKT_W - 1) / PKT_W, e = PKT_W - 1 - g;
-      const int lo0 = e * cl, nlo = max(0, min(nl, lo0 + cl) - lo0), hi0 = e * ch, nhi = max(0, min(nh, hi0 + ch) - hi0);
-      const int ncs = nlo + nhi;                                              // chunks of this step: low side first
-      // rows / columns beyond the strip or the sequence repeat the last one: their sums are never stored
-      const int il = min(16 * t + 1 + r, wid), jl = min(16 * bj + 1 + r, n_loc);
-      const int oA = ((-1 - il) * ld + c0 - 1 + il) * 8, oB = (int)tab * 8 + (jl * ld + c0 - 1) * 8;     // + m * (ld * 8)  |  - m * (ld - 1) * 8
+      int g;
+      const TileStep q = tile_step(k, o, g);
+#pragma unroll
+      for (int u = 0; u < PKT_DEPTH; u++) {
+        tq_a[o][u] = 0.0; tq_b[o][u] = 0.0;
+        if (q.on && u < q.ncs) tile_load(q, u, tq_a[o][u], tq_b[o][u]);
+      }
+    }
+  };
+  auto tile_finish = [&](const int k) {
+#pragma unroll
+    for (int o = 0; o < TOWN; o++) {
+      int g;
+      const TileStep q = tile_step(k, o, g);
+      if (!q.on) continue;
       f64x4 acc = tacc[o];
       if (g == 0) acc = f64x4{0.0, 0.0, 0.0, 0.0};
-      for (int c = 0; c < ncs; c += PKT_DEPTH) {
+#pragma unroll
+      for (int u = 0; u < PKT_DEPTH; u++)
+        if (u < q.ncs) acc = mfma_f64_16x16x4(tq_a[o][u], tq_b[o][u], acc);
+      for (int c = PKT_DEPTH; c < q.ncs; c += PKT_DEPTH) {                    // (long folds: more chunks per step than ride in registers)
         double a[PKT_DEPTH], b[PKT_DEPTH];
 #pragma unroll
         for (int u = 0; u < PKT_DEPTH; u++) {
           a[u] = 0.0; b[u] = 0.0;
-          if (c + u < ncs) {
-            const int cid = c + u < nlo ? lo0 + c + u : nch - 1 - (hi0 + c + u - nlo);
-            const int m = m_lo + 4 * cid + kk, mc = min(m, m_hi);
-            a[u] = buf_load_f64(rsQ, oA + mc * (ld * 8), 0);                 // QM(i, m - 1): own columns
-            b[u] = buf_load_f64_aux(rsQ, oB - mc * ((ld - 1) * 8), 0);       // QM1(m, j): maybe another strip's
-            if (m > m_hi) a[u] = 0.0;
-          }
+          if (c + u < q.ncs) tile_load(q, c + u, a[u], b[u]);
         }
 #pragma unroll
         for (int u = 0; u < PKT_DEPTH; u++)
-          if (c + u < ncs) acc = mfma_f64_16x16x4(a[u], b[u], acc);
+          if (c + u < q.ncs) acc = mfma_f64_16x16x4(a[u], b[u], acc);
       }
       tacc[o] = acc;
       if (g == PKT_W - 1) {
-        const int jj = 16 * bj + 1 + r;
+        const int r = lane & 15, kk = lane >> 4, jj = 16 * q.bj + 1 + r;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          const int ii = 16 * t + 1 + kk + 4 * rr;
+          const int ii = 16 * q.t + 1 + kk + 4 * rr;
           if (ii <= wid && jj <= n_loc) DFAR[(long long)(jj - ii) * ld + c0 - 1 + ii] = acc[rr];
         }
       }
     }
   };
+  auto tile_job = [&](const int k) { tile_issue(k); tile_finish(k); };
 
   bool failed = false;
   if (fin) {
@@ -683,7 +726,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         }
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
-      if (NFLOAT == 0 && k < n_loc) tile_job(k);
+      if (!TILE_ON_TOWERS && NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});            // help the sweep of diagonal k
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
@@ -692,7 +735,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     // ================= service waves
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (wave == w_svcA) service_a(k); else service_b(k);
-      if (PKT_SVC && k < n_loc) tile_job(k);
+      if ((PKT_SVC || TILE_ON_TOWERS) && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
@@ -700,7 +743,11 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   } else if (!pinned) {
     // ================= floating waves: items only
     for (int k = TURN + 1; k <= n_loc; k++) {
-      if (k < n_loc) { tile_job(k); run_items(k, std::true_type{}); }
+      if (k < n_loc) {
+        if (!TILE_ON_TOWERS && PKT_OVERLAP) { tile_issue(k); run_items(k, std::true_type{}, 1); tile_finish(k); }   // one item under the tile operands' round trip
+        else if (!TILE_ON_TOWERS) tile_job(k);
+        run_items(k, std::true_type{});
+      }
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
     }
@@ -717,14 +764,18 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     static_assert(((TURN + 1) & 1) == 0, "the loop below starts on an even diagonal");
     for (int k = TURN + 1; k <= n_loc; k += 2) {
       if (k < n_loc) {
+        if (TILE_ON_TOWERS) tile_issue(k);
         tower(k, GE);
+        if (TILE_ON_TOWERS) tile_finish(k);
         run_items(k, std::false_type{});
       }
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
       if (k + 1 > n_loc) break;
       if (k + 1 < n_loc) {
+        if (TILE_ON_TOWERS) tile_issue(k + 1);
         tower(k + 1, GO);
+        if (TILE_ON_TOWERS) tile_finish(k + 1);
         run_items(k + 1, std::false_type{});
       }
       STRIP_BARRIER();
