@@ -233,7 +233,9 @@ def launch_ranks(n):
         except subprocess.TimeoutExpired:
             p_.kill()
             rcs.append(-9)
-    sys.stdout.write(out0)
+    # ONE JSON line on stdout: whatever else rank 0 printed there (the gloo backend announces its connections on stdout) goes to stderr
+    for line in out0.splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
