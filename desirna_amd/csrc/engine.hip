@@ -34,7 +34,7 @@ using namespace drna;
 static std::string g_create_error;
 
 #ifndef DRNA_MFE_FARK_MIN_STRIPS
-#define DRNA_MFE_FARK_MIN_STRIPS 6
+#define DRNA_MFE_FARK_MIN_STRIPS 4
 #endif
 constexpr int MFE_FARK_MIN_STRIPS = DRNA_MFE_FARK_MIN_STRIPS;   // (measured: tools/time_strip_variants.py)
 struct drna_engine {
@@ -104,6 +104,7 @@ struct drna_engine {
   int strip_epoch = 0;            // grows by one per launch; flags and epoch go back to zero at STRIP_EPOCH_RESET
   int flag_resets = 0;            // times the hand-over flags were zeroed because an epoch neared the compare range
   int strip_fault = 0;            // option "strip_fault": inject a lost strip (tests)
+  bool cur_with_pf = false;       // the call being enqueued also folds the partition function
   int mfe_fark_min_strips = MFE_FARK_MIN_STRIPS;   // option "mfe_fark_min_strips": MFE strips fold in blocked form from this many strips on
   int mfe_split = 2;              // option "mfe_split": parts of a batch (on two streams) for the pseudoknot rounds of the strip path; 1 = off
   bool helper_fault = false;      // tests: the helper workgroups of the partition function leave at once (a lost partner)
@@ -223,7 +224,10 @@ static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, 
   lk.flags = e->d_sflags + ((size_t)e->max_R + first_slot) * STRIP_MAXS * 32;
   lk.base = next_strip_epoch(e);
   lk.nseq = nseq; lk.S = S; lk.idx = idx; lk.r0 = r0; lk.pad = strip_pad(S); lk.fault = e->strip_fault;
-  lk.fark = S >= e->mfe_fark_min_strips;           // blocked multiloop splits for the long folds (fold_mfe_strip.hpp, MKT_L)
+  // blocked multiloop splits for the long folds (fold_mfe_strip.hpp, MKT_L).  Alone they win from four strips on (400 nt x 256:
+  // 4.86 -> 4.48 ms); beside the partition function's strips only from five on (400 nt: both folds 9.31 -> 9.94 ms, 600 nt x 128:
+  // 11.3 -> 9.9 ms) -- unless the MFE fold is a chain of pseudoknot rounds, which then dominates the call (config 5: 10.4 -> 9.6 ms)
+  lk.fark = S >= e->mfe_fark_min_strips + ((e->cur_with_pf && a.pk_rounds == 0) ? 1 : 0);
   lk.dbg = e->d_sdbg ? e->d_sdbg + ((size_t)e->max_R + first_slot) * 8 : nullptr;
   lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
   if (lk.fark) hipLaunchKernelGGL((mfe_strip_kernel<1024, true>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
@@ -257,6 +261,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   e->cus = prop.multiProcessorCount;
   if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
   if (const char* hv = getenv("DRNA_PF_HELPER")) e->pf_helper = atoi(hv) != 0;
+  if (const char* fv = getenv("DRNA_MFE_FARK_MIN_STRIPS")) { const int v = atoi(fv); e->mfe_fark_min_strips = v < 1 ? 1 : v; }
   if (const char* sv = getenv("DRNA_STRIPS")) { const int v = atoi(sv); e->strips = v < 0 ? 0 : v > 2 ? 2 : v; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
@@ -442,6 +447,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->err = "drna_score_batch: DRNA_NEED_EVAL needs drna_set_targets() with the same L";
     return DRNA_ERR_ARG;
   }
+  e->cur_with_pf = want_pf;
   if (!e->in_fallback && e->solo_left > 0) {             // after repeated lost partners: one workgroup per fold for a while
     const int s_strips = e->strips;
     const bool s_dual = e->dual, s_help = e->pf_helper;
@@ -902,6 +908,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
     e->err = "drna_score_ragged: bad argument (R within the engine's limit; output pointers for every requested flag)";
     return DRNA_ERR_ARG;
   }
+  e->cur_with_pf = want_pf;
   if (!e->in_fallback && e->solo_left > 0) {             // (see drna_score_batch_device)
     const int s_strips = e->strips;
     e->in_fallback = true; e->strips = 0;

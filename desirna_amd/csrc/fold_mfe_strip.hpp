@@ -51,7 +51,13 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #ifndef DRNA_MKT_L
 #define DRNA_MKT_L 4
 #endif
-constexpr int MKT_W = DRNA_MKT_W, MKT_L = DRNA_MKT_L;
+#ifndef DRNA_MKT_TOWER
+#define DRNA_MKT_TOWER 1
+#endif
+#ifndef DRNA_MKT_DEPTH
+#define DRNA_MKT_DEPTH 2
+#endif
+constexpr int MKT_W = DRNA_MKT_W, MKT_L = DRNA_MKT_L, MKT_TOWER = DRNA_MKT_TOWER, MKT_DEPTH = DRNA_MKT_DEPTH;
 constexpr int MKT_BMIN = (44 + 2 * MKT_L + 15) / 16;          // smallest block distance with a far range
 static_assert(MKT_W >= 1 && MKT_W <= 16 && MKT_L >= 3, "see tools/pkt_schedule.py");
 
@@ -567,72 +573,102 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     sb_request(k + 1);              // column k-2: its cells (diagonals <= k-3) were stored in step k-2 and drained by its barrier
   };
 
-  // ---- tile products of the blocked form (see MKT_L above and fold_pf_strip.hpp).  Tile waves: the floating and the service waves
-  // (one tile row each), or the finalize waves of a workgroup that has neither.  At step k the tiles of block distance
-  // B = (k + 15 + MKT_W) >> 4 are in step g = (k + 15 + MKT_W) & 15 of their window (g < MKT_W).
+  // ---- tile products of the blocked form (see MKT_L above and fold_pf_strip.hpp).  Tile waves (MKT_TOWER): the tower waves and
+  // the service waves, one tile row each -- a tower wave requests its chunks' operands, runs its tower step (LDS work) under their
+  // round trip and folds them in afterwards (tile_issue / tile_finish); else the floating and the service waves; the finalize waves
+  // of a workgroup that has neither.  At step k the tiles of block distance B = (k + 15 + MKT_W) >> 4 are in step
+  // g = (k + 15 + MKT_W) & 15 of their window (g < MKT_W).
   constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * NG;
-  constexpr int NTW = NFLOAT > 0 ? NFLOAT + NSVC : NFIN;
+  constexpr bool TILE_ON_TOWERS = MKT_TOWER != 0;
+  constexpr int NTW = TILE_ON_TOWERS ? NFIN * NG + NSVC : NFLOAT > 0 ? NFLOAT + NSVC : NFIN;
   constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
-  const int tf = NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * NG : NFLOAT + wave - NFIN) : wave;
+  const int tf = TILE_ON_TOWERS ? (aw >= 0 ? aw : NFIN * NG + wave - NFIN)
+                                : NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * NG : NFLOAT + wave - NFIN) : wave;
   int tacc[TOWN][4];
 #pragma unroll
   for (int o = 0; o < TOWN; o++) { tacc[o][0] = INF; tacc[o][1] = INF; tacc[o][2] = INF; tacc[o][3] = INF; }
-  auto tile_job = [&](const int k) {
-    const int xk = k + 15 + MKT_W, B = xk >> 4, g = xk & 15;
-    if (!fark || (MSTRIP_SKIP & 16) || g >= MKT_W || B < MKT_BMIN) return;
+  constexpr int DEPTH = MKT_DEPTH;                                           // chunks in flight (two loads each)
+  int tq_a[TOWN][DEPTH], tq_b[TOWN][DEPTH];                                  // operands requested by tile_issue
+  struct TileStep { int t, bj, m_lo, m_hi, nch, lo0, nlo, hi0, ncs, oA, oB; bool on; };
+  auto tile_step = [&](const int k, const int o, int& g) -> TileStep {
+    TileStep q;
+    const int xk = k + 15 + MKT_W, B = xk >> 4;
+    g = xk & 15;
+    q.t = tf + NTW * o; q.bj = q.t + B;
+    q.on = fark && !(MSTRIP_SKIP & 16) && g < MKT_W && B >= MKT_BMIN && 16 * q.t < wid && 16 * q.bj + 1 <= n_loc;   // (wave-uniform)
+    q.m_lo = 16 * q.t + 31 + MKT_L; q.m_hi = 16 * q.bj - 13 - MKT_L;
+    q.nch = (q.m_hi - q.m_lo + 4) >> 2;
+    const int nl = (q.nch + 1) >> 1, nh = q.nch >> 1;
+    const int cl = (nl + MKT_W - 1) / MKT_W, ch = (nh + MKT_W - 1) / MKT_W, e = MKT_W - 1 - g;
+    q.lo0 = e * cl; q.nlo = max(0, min(nl, q.lo0 + cl) - q.lo0); q.hi0 = e * ch;
+    const int nhi = max(0, min(nh, q.hi0 + ch) - q.hi0);
+    q.ncs = q.nlo + nhi;                                                      // chunks of this step: low side first
+    // lane (h, x) loads fML(i_min + h + 4 (x >> 2), m - 1) for m = m0 + (x & 3) and fML(m0 + h, j_min + x); rows / columns
+    // beyond the strip or the sequence repeat the last one (their minima are never read)
     const int h = lane >> 4, x = lane & 15;
+    const int il = min(16 * q.t + 1 + h + 4 * (x >> 2), wid), jl = min(16 * q.bj + 1 + x, n_loc);
+    q.oA = ((-1 - il) * ld + c0 - 1 + il) * 4; q.oB = (jl * ld + c0 - 1) * 4;       // + m * (ld * 4)  |  - m * (ld - 1) * 4
+    return q;
+  };
+  auto tile_load = [&](const TileStep& q, const int c, int& a, int& b) {
+    const int cid = c < q.nlo ? q.lo0 + c : q.nch - 1 - (q.hi0 + c - q.nlo);
+    const int m0 = q.m_lo + 4 * cid, ma = m0 + (lane & 3), mb = m0 + (lane >> 4);
+    a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, q.oA + min(ma, q.m_hi) * (ld * 4), 0, 0);
+    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, q.oB - min(mb, q.m_hi) * ((ld - 1) * 4), 0, (STRIP_DIAG & 2) ? 0 : 16);
+    if (ma > q.m_hi) a = INF;
+    if (mb > q.m_hi) b = INF;
+  };
+  // one chunk into the four accumulators of lane (h, x): rows h + 4 rr, column x
+  auto tile_fold = [&](const int a, const int b, int& acc0, int& acc1, int& acc2, int& acc3) {
+    const int x = lane & 15;
+    const int b0 = lane_fetch_i32(b, x), b1 = lane_fetch_i32(b, 16 + x), b2 = lane_fetch_i32(b, 32 + x), b3 = lane_fetch_i32(b, 48 + x);
+    acc0 = min(acc0, min(min(row_bcast_i32<0>(a) + b0, row_bcast_i32<1>(a) + b1), min(row_bcast_i32<2>(a) + b2, row_bcast_i32<3>(a) + b3)));
+    acc1 = min(acc1, min(min(row_bcast_i32<4>(a) + b0, row_bcast_i32<5>(a) + b1), min(row_bcast_i32<6>(a) + b2, row_bcast_i32<7>(a) + b3)));
+    acc2 = min(acc2, min(min(row_bcast_i32<8>(a) + b0, row_bcast_i32<9>(a) + b1), min(row_bcast_i32<10>(a) + b2, row_bcast_i32<11>(a) + b3)));
+    acc3 = min(acc3, min(min(row_bcast_i32<12>(a) + b0, row_bcast_i32<13>(a) + b1), min(row_bcast_i32<14>(a) + b2, row_bcast_i32<15>(a) + b3)));
+  };
+  auto tile_issue = [&](const int k) {
 #pragma unroll
     for (int o = 0; o < TOWN; o++) {
-      const int t = tf + NTW * o, bj = t + B;
-      if (16 * t >= wid || 16 * bj + 1 > n_loc) continue;                   // (wave-uniform) no such tile in this strip / triangle
-      const int m_lo = 16 * t + 31 + MKT_L, m_hi = 16 * bj - 13 - MKT_L;
-      const int nch = (m_hi - m_lo + 4) >> 2, nl = (nch + 1) >> 1, nh = nch >> 1;
-      const int cl = (nl + MKT_W - 1) / MKT_W, ch = (nh + MKT_W - 1) / MKT_W, e = MKT_W - 1 - g;
-      const int lo0 = e * cl, nlo = max(0, min(nl, lo0 + cl) - lo0), hi0 = e * ch, nhi = max(0, min(nh, hi0 + ch) - hi0);
-      const int ncs = nlo + nhi;                                              // chunks of this step: low side first
-      // lane (h, x) loads fML(i_min + h + 4 (x >> 2), m - 1) for m = m0 + (x & 3) and fML(m0 + h, j_min + x); rows / columns
-      // beyond the strip or the sequence repeat the last one (their minima are never read)
-      const int il = min(16 * t + 1 + h + 4 * (x >> 2), wid), jl = min(16 * bj + 1 + x, n_loc);
-      const int oA = ((-1 - il) * ld + c0 - 1 + il) * 4, oB = (jl * ld + c0 - 1) * 4;       // + m * (ld * 4)  |  - m * (ld - 1) * 4
+      int g;
+      const TileStep q = tile_step(k, o, g);
+#pragma unroll
+      for (int u = 0; u < DEPTH; u++) {
+        tq_a[o][u] = INF; tq_b[o][u] = INF;
+        if (q.on && u < q.ncs) tile_load(q, u, tq_a[o][u], tq_b[o][u]);
+      }
+    }
+  };
+  auto tile_finish = [&](const int k) {
+#pragma unroll
+    for (int o = 0; o < TOWN; o++) {
+      int g;
+      const TileStep q = tile_step(k, o, g);
+      if (!q.on) continue;
       int acc0 = tacc[o][0], acc1 = tacc[o][1], acc2 = tacc[o][2], acc3 = tacc[o][3];
       if (g == 0) { acc0 = INF; acc1 = INF; acc2 = INF; acc3 = INF; }
-      constexpr int DEPTH = 8;                                                // chunks in flight (16 loads)
-      for (int c = 0; c < ncs; c += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; u++)
+        if (u < q.ncs) tile_fold(tq_a[o][u], tq_b[o][u], acc0, acc1, acc2, acc3);
+      for (int c = DEPTH; c < q.ncs; c += DEPTH) {                            // (long folds: more chunks per step than ride in registers)
         int av[DEPTH], bv[DEPTH];
 #pragma unroll
         for (int u = 0; u < DEPTH; u++) {
           av[u] = INF; bv[u] = INF;
-          if (c + u < ncs) {
-            const int cid = c + u < nlo ? lo0 + c + u : nch - 1 - (hi0 + c + u - nlo);
-            const int m0 = m_lo + 4 * cid;
-            const int ma = m0 + (x & 3), mb = m0 + h;
-            av[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, oA + min(ma, m_hi) * (ld * 4), 0, 0);
-            bv[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, oB - min(mb, m_hi) * ((ld - 1) * 4), 0, (STRIP_DIAG & 2) ? 0 : 16);
-            if (ma > m_hi) av[u] = INF;
-            if (mb > m_hi) bv[u] = INF;
-          }
+          if (c + u < q.ncs) tile_load(q, c + u, av[u], bv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < DEPTH; u++) {
-          if (c + u < ncs) {
-            // second operands of the lane's column for the chunk's four split points; first operands by row broadcast
-            const int b0 = lane_fetch_i32(bv[u], x), b1 = lane_fetch_i32(bv[u], 16 + x), b2 = lane_fetch_i32(bv[u], 32 + x),
-                      b3 = lane_fetch_i32(bv[u], 48 + x);
-            const int a = av[u];
-            acc0 = min(acc0, min(min(row_bcast_i32<0>(a) + b0, row_bcast_i32<1>(a) + b1), min(row_bcast_i32<2>(a) + b2, row_bcast_i32<3>(a) + b3)));
-            acc1 = min(acc1, min(min(row_bcast_i32<4>(a) + b0, row_bcast_i32<5>(a) + b1), min(row_bcast_i32<6>(a) + b2, row_bcast_i32<7>(a) + b3)));
-            acc2 = min(acc2, min(min(row_bcast_i32<8>(a) + b0, row_bcast_i32<9>(a) + b1), min(row_bcast_i32<10>(a) + b2, row_bcast_i32<11>(a) + b3)));
-            acc3 = min(acc3, min(min(row_bcast_i32<12>(a) + b0, row_bcast_i32<13>(a) + b1), min(row_bcast_i32<14>(a) + b2, row_bcast_i32<15>(a) + b3)));
-          }
-        }
+        for (int u = 0; u < DEPTH; u++)
+          if (c + u < q.ncs) tile_fold(av[u], bv[u], acc0, acc1, acc2, acc3);
       }
       tacc[o][0] = acc0; tacc[o][1] = acc1; tacc[o][2] = acc2; tacc[o][3] = acc3;
       if (g == MKT_W - 1) {                    // accumulator rr of lane (h, x): cell (row h + 4 rr, column x) of the tile
-        int* slot = sm.dfar[t][bj & 1] + h * 16 + x;
+        int* slot = sm.dfar[q.t][q.bj & 1] + (lane >> 4) * 16 + (lane & 15);
         slot[0] = acc0; slot[64] = acc1; slot[128] = acc2; slot[192] = acc3;
       }
     }
   };
+  auto tile_job = [&](const int k) { tile_issue(k); tile_finish(k); };
 
   bool failed = false;
 #ifdef MSTRIP_STAMPS
@@ -701,7 +737,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
       MST(0);
-      if (NFLOAT == 0 && k < n_loc) tile_job(k);
+      if (!TILE_ON_TOWERS && NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       MST(1);
       STRIP_BARRIER();
@@ -722,7 +758,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   } else if (!pinned) {
     // ================= floating waves: tile products and items
     for (int k = TURN + 1; k <= n_loc; k++) {
-      if (k < n_loc) { tile_job(k); run_items(k, std::true_type{}); }
+      if (k < n_loc) { if (!TILE_ON_TOWERS) tile_job(k); run_items(k, std::true_type{}); }
       MST(1);
       STRIP_BARRIER();
       MST(2);
@@ -737,7 +773,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     static_assert(((TURN + 1) & 1) == 0, "the loop below starts on an even diagonal");
     for (int k = TURN + 1; k <= n_loc; k += 2) {
       if (k < n_loc) {
+        if (TILE_ON_TOWERS) tile_issue(k);
         mstrip_tower(sm, GE, k, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        if (TILE_ON_TOWERS) tile_finish(k);
         MST(0);
         run_items(k, std::false_type{});
         MST(1);
@@ -747,7 +785,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       if (sm.sync_fail[k & 1]) { failed = true; break; }
       if (k + 1 > n_loc) break;
       if (k + 1 < n_loc) {
+        if (TILE_ON_TOWERS) tile_issue(k + 1);
         mstrip_tower(sm, GO, k + 1, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
+        if (TILE_ON_TOWERS) tile_finish(k + 1);
         MST(0);
         run_items(k + 1, std::false_type{});
         MST(1);

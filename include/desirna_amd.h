@@ -184,8 +184,9 @@ int drna_last_edef_timing(const drna_engine *e, float out[2]);
  * 2 = two strips also for 64 < n <= 200 (diagnostics).  DRNA_STRIPS in the environment sets the default.
  * "pf_helper" (default 1): batches small enough to leave CUs idle (2 R + the MFE fold's workgroups <= CUs, 120 <= n <= 200) fold the
  * partition function with a helper workgroup per sequence that takes the far multiloop split points; Epf is bit-identical either way.
- * "mfe_fark_min_strips" (default 6, i.e. n > 600): from this many strips on the MFE strips fold their multiloop splits in blocked
- * form (16 x 16 tiles, the far split points as (min,+) tile products); results are identical either way.
+ * "mfe_fark_min_strips" (default 4, i.e. n > 360; one more beside a partition function when there are no pseudoknot rounds):
+ * from this many strips on the MFE strips fold their multiloop splits in blocked form (16 x 16 tiles, the far split points as
+ * (min,+) tile products); results are identical either way.
  * "mfe_split" (default 2): with pseudoknot rounds the strip path takes a fill launch and a traceback launch per round; a batch of
  * >= 32 sequences then goes in two halves on two streams so that one half's traceback runs under the other's fill; 1 = one part.
  */

@@ -696,7 +696,7 @@ def test_strip_kernels_equal_one_workgroup_kernels(eng400, oracle):
 
 
 def test_blocked_mfe_strips_equal_plain_strips(eng400, oracle):
-    """From six strips on (n > 600) the MFE strips fold their multiloop splits in blocked form (tile products of the far split
+    """From four strips on (n > 360) the MFE strips fold their multiloop splits in blocked form (tile products of the far split
     points, fold_mfe_strip.hpp MKT_L).  Forced here for two to four strips ("mfe_fark_min_strips" = 2), with pseudoknot rounds and
     a batch above one workgroup per CU: structures and energies must equal the plain strips' and the oracle's; and 700 nt through
     the default switch against the general kernel."""
@@ -711,7 +711,7 @@ def test_blocked_mfe_strips_equal_plain_strips(eng400, oracle):
             b = eng400.score_batch(seqs, flags)
             c = eng400.score_batch(seqs, flags)
         finally:
-            eng400.set_option("mfe_fark_min_strips", 6)
+            eng400.set_option("mfe_fark_min_strips", 4)
         assert a["mfe_ss"] == b["mfe_ss"] == c["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all() and (b["Emfe"] == c["Emfe"]).all()
         for k in (0, R - 1):
             ss, e = oracle.mfe(seqs[k])
