@@ -245,7 +245,7 @@ def test_pf_strip_kernel_blocked_sums(blob, oracle, flags, tag):
     of block distance 5 .. 9 have far ranges of up to 90 split points; a second window length moves every boundary."""
     e = Emu(blob, flags=flags, tag=tag) if flags else Emu(blob)
     rng = np.random.default_rng(4113)
-    seqs = [_rand(rng, 150, "GGCCAU"), _rand(rng, 150, "ACGU")]
+    seqs = [_rand(rng, 150, "GGCCAU" if flags else "ACGU")]
     Ep, st = e.pf_strip(seqs, 3, nt=256, calls=1)
     assert (st == 0).all()
     for k, s in enumerate(seqs):
