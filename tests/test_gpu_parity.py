@@ -718,13 +718,20 @@ def test_blocked_mfe_strips_equal_plain_strips(eng400, oracle):
             if pk:
                 ss = oracle.pk_struct(seqs[k], ss)
             assert b["mfe_ss"][k] == ss and int(b["Emfe"][k]) == e
-    eng = E.Engine(max_R=3, max_L=700, device=0)
+    eng = E.Engine(max_R=8, max_L=700, device=0)
     seqs = [_rand(rng, 700) for _ in range(3)]
     a = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PK)
+    # a ragged call: 6, 4, 4, 3 and 1 strips side by side (blocked from four on), with and without the partition function beside them
+    rs = [_rand(rng, n) for n in (700, 450, 371, 260, 130)]
+    r1 = eng.score_ragged(rs, flags=E.NEED_MFE)
+    r2 = eng.score_ragged(rs, flags=E.NEED_MFE | E.NEED_PF)
     eng.set_option("strips", 0)
     b = eng.score_batch(seqs, E.NEED_MFE | E.NEED_PK)
+    r0 = eng.score_ragged(rs, flags=E.NEED_MFE | E.NEED_PF)
     eng.close()
     assert a["mfe_ss"] == b["mfe_ss"] and (a["Emfe"] == b["Emfe"]).all()
+    assert r1["mfe_ss"] == r0["mfe_ss"] == r2["mfe_ss"] and list(r1["Emfe"]) == list(r0["Emfe"]) == list(r2["Emfe"])
+    assert np.abs(np.array(r2["Epf"]) - np.array(r0["Epf"])).max() < 1e-9
 
 
 def test_lost_strip_falls_back_to_one_workgroup_per_fold(eng400, oracle):

@@ -10,13 +10,14 @@ for L, R in cases:
     seqs = ["".join(rs.choice(list("ACGU"), L)) for _ in range(R)]
     eng = E.Engine(max_R=R, max_L=400 if L <= 400 else L)
     row = []
-    for thr in (99, 4):
+    for thr in (99, int(os.environ.get("THR", "3"))):
         eng.set_option("mfe_fark_min_strips", thr)
         for what, flags in (("mfe", E.NEED_MFE), ("both", E.NEED_MFE | E.NEED_PF)):
             ts = []
             for _ in range(4):
                 eng.score_batch(seqs, flags)
-                ts.append(eng.last_timing()["total"])
-            row.append("%s[%d] %.3f" % (what, thr, min(ts[1:])))
+                ts.append(eng.last_timing())
+            b = min(ts[1:], key=lambda t: t["total"])
+            row.append("%s[%d] %.3f (mfe %.2f pf %.2f)" % (what, thr, b["total"], b["mfe"], b["pf"]))
     print("L=%d R=%d  %s" % (L, R, "  ".join(row)), flush=True)
     eng.close()
