@@ -73,6 +73,7 @@ struct drna_engine {
   double* d_ws_out = nullptr;
   double* d_edef = nullptr;
   hipEvent_t ev_o0 = nullptr, ev_o1 = nullptr, ev_o2 = nullptr;
+  hipEvent_t ev_gate = nullptr;                // the partition function's launch waits for it (see pf_gate_round)
   float timing_edef[2] = {0, 0};
   // ragged batches: per-sequence descriptors (len, off, target, two index lists) and the structures' pair tables
   int* d_rg = nullptr;
@@ -216,7 +217,7 @@ static void launch_pf_strips(drna_engine* e, const PfArgs& a, int nseq, int S, i
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
 // one pseudoknot round of nseq sequences (slots first_slot ...; idx = their sequence numbers, or null: sequences r0 ...)
 static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, int r0,
-                                    hipStream_t st, int round) {
+                                    hipStream_t st, int round, hipEvent_t after_fill = nullptr) {
   StripRec xr;
   xr.rec = e->d_srec; xr.stride = e->srec_stride;
   const int groups = (nseq + 7) / 8;
@@ -232,6 +233,7 @@ static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, 
   lk.clk = e->d_sclk ? e->d_sclk + (size_t)first_slot * STRIP_MAXS * 2 : nullptr;
   if (lk.fark) hipLaunchKernelGGL((mfe_strip_kernel<1024, true>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
   else hipLaunchKernelGGL((mfe_strip_kernel<1024, false>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
+  if (after_fill) (void)hipEventRecord(after_fill, st);
   hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round, r0);
 }
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
@@ -261,6 +263,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   e->cus = prop.multiProcessorCount;
   if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
   if (const char* hv = getenv("DRNA_PF_HELPER")) e->pf_helper = atoi(hv) != 0;
+  if (const char* mv = getenv("DRNA_MFE_SPLIT")) { const int v = atoi(mv); e->mfe_split = v < 1 ? 1 : v > 8 ? 8 : v; }
   if (const char* fv = getenv("DRNA_MFE_FARK_MIN_STRIPS")) { const int v = atoi(fv); e->mfe_fark_min_strips = v < 1 ? 1 : v; }
   if (const char* sv = getenv("DRNA_STRIPS")) { const int v = atoi(sv); e->strips = v < 0 ? 0 : v > 2 ? 2 : v; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
@@ -307,7 +310,7 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   HIP_TRY(hipStreamCreateWithFlags(&e->s_eval, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&e->ev_mfe2, hipEventDisableTiming));
   hipEvent_t* evs[] = {&e->ev_start, &e->ev_end, &e->ev_m0, &e->ev_m1, &e->ev_p0, &e->ev_p1, &e->ev_e0, &e->ev_e1,
-                       &e->ev_o0, &e->ev_o1, &e->ev_o2};
+                       &e->ev_o0, &e->ev_o1, &e->ev_o2, &e->ev_gate};
   for (hipEvent_t* ev : evs) HIP_TRY(hipEventCreate(ev));
   return DRNA_OK;
 }
@@ -343,7 +346,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   for (hipStream_t s : ss)
     if (s) (void)hipStreamDestroy(s);
   hipEvent_t evs[] = {e->ev_start, e->ev_end, e->ev_m0, e->ev_m1, e->ev_p0, e->ev_p1, e->ev_e0, e->ev_e1,
-                      e->ev_o0, e->ev_o1, e->ev_o2};
+                      e->ev_o0, e->ev_o1, e->ev_o2, e->ev_gate};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   delete e;
@@ -543,12 +546,22 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     a.seqs = d_seqs; a.pt = e->d_pt; a.L = L; a.n_targets = e->n_targets; a.Ed = d_Ed;
     return a;
   };
+  // An MFE fold with pseudoknot rounds on the strip path is a chain of launches whose later links are sparse (only sequences that
+  // found a pair fold again), the partition function is one dense launch.  On a chip the first fill already fills (R x strips >=
+  // CUs) the partition function is therefore started when the last-but-one round has been queued: it runs beside the sparse rounds
+  // instead of halving the CUs of the dense first ones (400 nt x 128: 10.6 -> 9.0 ms, x 256: 19.3 -> 16.5 ms; on a chip with idle CUs
+  // it would only delay the partition function: 400 nt x 32 5.4 -> 5.7 ms).  DRNA_PF_GATE=-1 switches it off, k >= 0 forces round k.
+  static const int pf_gate_env = getenv("DRNA_PF_GATE") ? atoi(getenv("DRNA_PF_GATE")) : -2;
+  int pf_gate_round = -1;
+  static const int pf_gate_part = getenv("DRNA_PF_GATE_PART") ? atoi(getenv("DRNA_PF_GATE_PART")) : 0;
+  bool pf_gated = false;
   auto enqueue_pf = [&]() -> int {
     PfArgs a;
     a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
     a.seqs = d_seqs; a.L = L; a.ld = ld;
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
+    if (pf_gated) HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_gate, 0));
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
     e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
@@ -585,9 +598,15 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
       // every round is a fill launch and a traceback launch (one wave per sequence, ~0.2 ms with the chip idle): the batch goes
       // in parts on two streams, so that one part's traceback runs under another part's fill
       const int np = e->mfe_split, per = ((R + np - 1) / np + 7) / 8 * 8;
-      for (int round = 0; round <= a.pk_rounds; round++)
-        for (int part = 0, r0 = 0; r0 < R; part++, r0 += per)
-          launch_mfe_strips_round(e, a, std::min(per, R - r0), mfe_strips, r0, nullptr, r0, (part & 1) ? e->s_eval : e->s_mfe, round);
+      pf_gate_round = pf_gate_env >= -1 ? pf_gate_env : (pf_strips && R * mfe_strips >= e->cus && a.pk_rounds >= 2) ? a.pk_rounds - 1 : -1;
+      for (int round = 0; round <= a.pk_rounds; round++) {
+        for (int part = 0, r0 = 0; r0 < R; part++, r0 += per) {
+          const bool gate_here = round == pf_gate_round && want_pf && part == pf_gate_part;
+          launch_mfe_strips_round(e, a, std::min(per, R - r0), mfe_strips, r0, nullptr, r0, (part & 1) ? e->s_eval : e->s_mfe, round,
+                                  gate_here ? e->ev_gate : nullptr);
+          if (gate_here) pf_gated = true;
+        }
+      }
       HIP_TRY(hipEventRecord(e->ev_mfe2, e->s_eval));
       HIP_TRY(hipStreamWaitEvent(e->s_mfe, e->ev_mfe2, 0));
     } else if (mfe_strips) launch_mfe_strips(e, a, R, mfe_strips, 0, nullptr, e->s_mfe);
