@@ -146,7 +146,7 @@ def cpu_baseline(seqs, target, budget_s=25.0):
             "single_core_value": single, "effective_cores": allc / single, "scaling_table": table}, ref
 
 
-def roofline_block(dom, dom_ms, L, R, tk):
+def roofline_block(dom, dom_ms, L, R, tk, fused=False):
     """The dominant fold kernel against HARDWARE peaks only -- `bound` is the largest of
          hbm : measured HBM bytes per launch (PMC: (2 FETCH_SIZE + WRITE_SIZE) KB) / kernel time / 8 TB/s
          lds : LDS-array busy cycles per CU (SQ_LDS_IDX_ACTIVE / workgroups) / kernel cycles at 2.4 GHz
@@ -209,13 +209,103 @@ def roofline_block(dom, dom_ms, L, R, tk):
     return out
 
 
+def mc_loop_block(eng, target, R, iters, kernel_only_rate, headline_kernel_ms=None, seed=1):
+    """The loop the reference actually runs (utils/replica_exchange_monte_carlo.py:176-210: propose -> score -> accept, e times per
+    exchange step) through the native driver drna_mc_run, on the benchmark's target: every iteration proposes one mutation per
+    replica (utils/sequence_utils.py:1008-1136), folds the R proposals on the GPU, computes SimScore and the -sf sum, and takes
+    the Metropolis decision.  All replicas start from the reference's initial sequence; one untimed exchange step (warm-up, and
+    the replicas diverge), then `iters` timed iterations.  Outside the headline's timed region."""
+    import random
+    from desirna_amd import design, engine as E, replica_exchange as rx
+    L = len(target)
+    prob = design.DesignProblem(target, "N" * L, None)
+    hk = E.HostKernels()
+    flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL
+    sf = [("Ed-Epf", 1.0)]
+    init = prob.initial_sequence(random.Random(2137 + seed))
+    cur = np.ascontiguousarray(np.tile(np.frombuffer(init.encode(), dtype=np.uint8), (R, 1)))
+    Epf, Emfe, ss, Ed = eng.score_batch_arrays(cur, flags)
+    mcc, _, _ = hk.simscore(target, ss)
+    state = dict(seqs=cur, mfe_ss=np.ascontiguousarray(ss), score=np.ascontiguousarray(Ed[:, 0] / 100.0 - Epf),
+                 mcc1=np.ascontiguousarray(1.0 - mcc), Epf=np.ascontiguousarray(Epf), Ed=np.ascontiguousarray(Ed[:, 0] / 100.0))
+    temps = np.array(rx.get_rep_temps(R, 10.0, 150.0), dtype=np.float64)
+    shelf = np.searchsorted(temps, temps).astype(np.int32)
+    rng_state = np.empty((R, E.RNG_WORDS), dtype=np.uint32)
+    counters = np.zeros(3, dtype=np.int64)
+    k0 = int(np.lexsort((state["score"], state["mcc1"]))[0])
+    best = dict(seq=cur[k0].copy(), ss=state["mfe_ss"][k0].copy(),
+                vals=np.array([state["mcc1"][k0], state["score"][k0], state["Epf"][k0], state["Ed"][k0]], dtype=np.float64))
+
+    def exchange_step(n):
+        hk.rng_seed(np.arange(R), out=rng_state)               # random.seed(replica index) at every exchange step
+        eng.mc_run(prob, n, shelf, R, 0.7, 0.0, True, temps, sf, flags, rng_state, state, counters, best)
+
+    exchange_step(iters)                                       # untimed
+    counters[:] = 0
+    eng.timing_sums(reset=True)
+    t0 = time.perf_counter()
+    exchange_step(iters)
+    dt = time.perf_counter() - t0
+    ts = eng.timing_sums()
+    ms_it = dt / iters * 1e3
+    k_ms = ts["total"] / max(1, ts["calls"])
+    rate = R * iters / dt
+    return {"scored_sequences_per_s": rate, "ms_per_iteration": ms_it, "kernel_ms_per_iteration": k_ms,
+            "host_us_per_iteration": (ms_it - k_ms) * 1e3, "iterations": iters, "replicas": R, "L": L,
+            # the headline's rate (uniform-random sequences; a converging design's sequences fold a few per cent faster) and the rate
+            # the same iterations would have with no host work between the launches beyond the headline's own (device time of these
+            # iterations + the headline's host time per step)
+            "frac_of_kernel_only_rate": rate / kernel_only_rate if kernel_only_rate else None,
+            "frac_of_own_device_rate": (k_ms + (R / kernel_only_rate * 1e3 - headline_kernel_ms)) / ms_it
+                                       if kernel_only_rate and headline_kernel_ms else None,
+            "host_threads": eng.get_option("mc_threads_used"),
+            "accepted": int(counters[0]), "rejected": int(counters[2]), "best_1_minus_mcc": float(best["vals"][0]),
+            "what": "drna_mc_run: proposals (reference MT19937 streams) + GPU folds + SimScore + -sf Ed-Epf + Metropolis, e=%d "
+                    "iterations of one exchange step after one untimed step; host_us = wall - device time per iteration" % iters}
+
+
+def r_sweep_block(target, device, Rs=(32, 64, 128, 256), reps=12):
+    """Replicas per call at the headline's shape (one GPU): device-resident batches of R uniform-random sequences, the time of a
+    whole scoring call (both folds + E(target)), best of `reps` after three warm-up calls.  R = 64 is the headline's operating
+    point (four workgroups per sequence); above it every fold has one workgroup and the chip is shared by more folds."""
+    import torch
+    from desirna_amd import engine as E
+    L = len(target)
+    rows = []
+    dev = torch.device("cuda", device)
+    for R in Rs:
+        rng = np.random.default_rng(20260101)
+        seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
+        eng = E.Engine(max_R=R, max_L=L, device=device)
+        eng.set_targets([target])
+        d_seqs = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()).to(dev)
+        d_Epf = torch.zeros(R, dtype=torch.float64, device=dev); d_Emfe = torch.zeros(R, dtype=torch.int32, device=dev)
+        d_ss = torch.zeros(R * L, dtype=torch.uint8, device=dev); d_Ed = torch.zeros(R, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        best, kt = None, None
+        for k in range(reps + 3):
+            t0 = time.perf_counter()
+            eng.score_batch_device(d_seqs.data_ptr(), R, L, E.NEED_PF | E.NEED_MFE | E.NEED_EVAL, d_Epf.data_ptr(), d_Emfe.data_ptr(),
+                                   d_ss.data_ptr(), d_Ed.data_ptr())
+            dt = time.perf_counter() - t0
+            if k >= 3 and (best is None or dt < best):
+                best, kt = dt, eng.last_timing()
+        rows.append({"R": R, "ms_per_call": best * 1e3, "replica_folds_per_s": R / best, "mfe_ms": kt["mfe"], "pf_ms": kt["pf"],
+                     "workgroups": eng.get_option("last_workgroups"), "sync_fallbacks": eng.get_option("sync_fallbacks")})
+        eng.close()
+    return rows
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks from here, one process
     per GPU, as torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's JSON
     line and return non-zero if any rank failed.  This parent imports neither torch nor the engine and never touches the GPU;
-    the ranks are plain child processes (nothing is exec'ed over an initialised process)."""
+    the ranks are plain child processes (nothing is exec'ed over an initialised process).  All ranks are supervised: the first
+    rank that exits non-zero, or the deadline, ends the others (a rank that dies at start-up would otherwise leave the rest in
+    the rendezvous until the backend's own timeout); rank 0's stdout is drained by a thread meanwhile."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -224,24 +314,53 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = []
-    deadline = time.time() + 1800
-    for p_ in procs:
-        try:
-            rcs.append(p_.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p_.kill()
-            rcs.append(-9)
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("DRNA_BENCH_LAUNCH_TIMEOUT", "1800"))
+    rcs = [None] * n
+    why = None
+    while any(c is None for c in rcs):
+        for k, p_ in enumerate(procs):
+            if rcs[k] is None:
+                rcs[k] = p_.poll()
+        failed = [k for k, c in enumerate(rcs) if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            why = "rank %d exited with code %s" % (failed[0], rcs[failed[0]]) if failed else "deadline reached"
+            for k, p_ in enumerate(procs):
+                if rcs[k] is None:
+                    p_.kill()                                  # the exact child processes started above
+                    p_.wait()
+                    rcs[k] = -9
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = b"".join(chunks).decode()
     # ONE JSON line on stdout: whatever else rank 0 printed there (the gloo backend announces its connections on stdout) goes to stderr
     for line in out0.splitlines():
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s%s\n" % (bad, " -- the others were stopped: " + why if why else ""))
         return 1
     return 0
+
+
+def strong_shard(R_total, rank, world):
+    """--scaling strong: the reference's R is the TOTAL number of replicas (utils/replica_exchange_monte_carlo.py:233-271);
+    replica r lives on rank r mod world (replica_exchange.ReplicaShards)."""
+    return list(range(rank, R_total, world))
+
+
+def oracle_reference(seqs, target):
+    """The CPU oracle's answers (Epf, Emfe, structures, E(target)) for a batch: the checker of the timed GPU path."""
+    from desirna_amd import params
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = pyoracle.Oracle(params.load_blob())
+    cores, _ = usable_cores()
+    return orc.score_batch(list(seqs), [target], pyoracle.FLAG_PF | pyoracle.FLAG_MFE, threads=cores)
 
 
 def main():
@@ -249,21 +368,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--replicas", type=int, default=64, help="replicas per GPU")
+    ap.add_argument("--replicas", type=int, default=64, help="replicas per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --replicas per GPU (the headline's R = 64 on every GPU); strong: --replicas in TOTAL, replica r on rank r mod N")
     ap.add_argument("--target", default="eteV1_69.txt", help="Eterna100-V1 target giving L (69: L=200, 92: L=100, 53: L=400)")
     ap.add_argument("--exchange-every", type=int, default=100)
     ap.add_argument("--seqs", choices=["uniform", "design"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mc-loop", action="store_true", help="skip the end-to-end Monte-Carlo loop figure (mc_loop)")
+    ap.add_argument("--r-sweep", action="store_true", help="add the replicas-per-call sweep (32 / 64 / 128 / 256) to the line (N = 1)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))        # before torch / HIP are touched in this process
     if os.environ.get("DRNA_BENCH_ECHO_RANK"):           # tests/test_host_cpu.py: what a rank was started with, no GPU needed
         me = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         me["gpus"] = args.gpus
+        me["scaling"] = args.scaling
+        me["local_replicas"] = (len(strong_shard(args.replicas, int(me["RANK"] or 0), int(me["WORLD_SIZE"] or 1)))
+                                if args.scaling == "strong" else args.replicas)
         with open(os.path.join(os.environ["DRNA_BENCH_ECHO_RANK"], "rank%s.json" % me["RANK"]), "w") as fh:
             json.dump(me, fh)
         if me["RANK"] in (None, "0"):
             print(json.dumps(me))
+        if os.environ.get("DRNA_BENCH_ECHO_HANG") == me["RANK"]:
+            time.sleep(600)                              # a rank stuck in the rendezvous (test of the launcher's supervision)
         raise SystemExit(3 if os.environ.get("DRNA_BENCH_ECHO_FAIL") == me["RANK"] else 0)
 
     import torch
@@ -307,15 +435,31 @@ def main():
 
     from desirna_amd import engine as E
     target = load_target(args.target)
-    L, R = len(target), args.replicas
-    rng = np.random.default_rng(20260101 + rank)
+    L = len(target)
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE set of --replicas sequences for the whole job, replica r on rank r mod N
+        rng = np.random.default_rng(20260101)
+        n_all = args.replicas
+        mine = strong_shard(n_all, rank, world)
+    else:
+        rng = np.random.default_rng(20260101 + rank)
+        n_all = args.replicas
+        mine = list(range(n_all))
     if args.seqs == "uniform":
-        seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
+        all_seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(n_all)]
     else:
         from desirna_amd.workloads import design_like_sequences
-        seqs = design_like_sequences(target, R, rng)
-    eng = E.Engine(max_R=R, max_L=L, device=local_rank)
-    if backend == "gloo" and world > max(1, torch.cuda.device_count()):
+        all_seqs = design_like_sequences(target, n_all, rng)
+    seqs = [all_seqs[k] for k in mine]
+    R = len(seqs)
+    R_total = args.replicas if strong else args.replicas * world
+    R_max = -(-args.replicas // world) if strong else args.replicas          # widest shard: the all-gather's row width
+    if R < 1:
+        raise SystemExit("bench.py: --scaling strong with fewer replicas than ranks leaves rank %d empty" % rank)
+    eng = E.Engine(max_R=max(R, 1), max_L=L, device=local_rank)
+    shared_card = backend == "gloo" and world > max(1, torch.cuda.device_count())
+    if shared_card:
         # rehearsal with several ranks on ONE card: the folds by several workgroups assume the whole chip (every workgroup of a
         # launch resident at once), which ranks sharing a card do not have
         eng.set_option("pf_helper", 0)
@@ -328,16 +472,22 @@ def main():
     d_Emfe = torch.zeros(R, dtype=torch.int32, device=dev)
     d_ss = torch.zeros(R * L, dtype=torch.uint8, device=dev)
     d_Ed = torch.zeros(R, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(R * world, dtype=torch.float64, device=cdev) if multi else None
+    gathered = torch.zeros(R_max * world, dtype=torch.float64, device=cdev) if multi else None
+    mine_row = torch.full((R_max,), float("nan"), dtype=torch.float64, device=cdev) if multi else None
     torch.cuda.synchronize()
+    gather_s = [0.0, 0]                                            # wall seconds inside the exchange step's all-gather, calls
 
     def step(k, last):
         eng.score_batch_device(d_seqs.data_ptr(), R, L, flags, d_Epf.data_ptr(), d_Emfe.data_ptr(),
                                d_ss.data_ptr(), d_Ed.data_ptr())
         if multi and (last or (k + 1) % args.exchange_every == 0):
+            tg0 = time.perf_counter()
             score = d_Ed.to(torch.float64) / 100.0 - d_Epf          # Ed - Epf, the default -sf term
-            dist.all_gather_into_tensor(gathered, score.to(cdev))
+            mine_row[:R] = score.to(cdev)
+            dist.all_gather_into_tensor(gathered, mine_row)         # ONE collective per exchange step
             torch.cuda.current_stream().synchronize()               # d_Ed / d_Epf are read: the next step's kernels (other streams) overwrite them
+            gather_s[0] += time.perf_counter() - tg0
+            gather_s[1] += 1
 
     for k in range(args.warmup):
         step(k, False)
@@ -346,46 +496,76 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.timing_sums(reset=True)                     # the engine sums its HIP-event kernel times over the timed calls itself
+    gather_s[0], gather_s[1] = 0.0, 0
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, k == args.steps - 1)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0               # this rank's own clock, before it waits for the others
     if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # every rank's own time per step and time in the all-gather (outside the timed region: reporting only)
+        mine_t = torch.tensor([dt_own / args.steps * 1e3, gather_s[0] / max(1, gather_s[1]) * 1e6], dtype=torch.float64, device=cdev)
+        all_t = torch.zeros(2 * world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        per_rank = all_t.cpu().numpy().reshape(world, 2)
     ts = eng.timing_sums()
     for key in tk:
         tk[key] = ts[key] / max(1, ts["calls"])
 
     if rank == 0:
-        folds = R * world * args.steps
+        folds = R_total * args.steps
         dom = "pf" if tk["pf"] >= tk["mfe"] else "mfe"
+        fused = bool(eng.get_option("last_fused"))
         out = {
-            "metric": "replica-folds/sec (MFE+PF, L=%d, R=%d)" % (L, R),
+            "metric": "replica-folds/sec (MFE+PF, L=%d, R=%d)" % (L, args.replicas),
             "value": folds / dt, "unit": "replica-folds/s", "n_gpus": world, "collectives": (backend if multi else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32 (MFE) + f64 (PF)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Eterna100-V1 #%s target (L=%d), R=%d %s-random sequences per GPU, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int32 (MFE) + f64 (PF)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Eterna100-V1 #%s target (L=%d), R=%d %s-random sequences %s, "
                                    "-sf Ed-Epf (MFE fill+traceback, PF inside, eval_structure)"
-                                   % (args.target[6:8], L, R, args.seqs),
-                       "replicas_per_gpu": R, "L": L, "exchange_every": args.exchange_every,
-                       "threads_per_workgroup": eng.info()["threads_per_wg"]},
+                                   % (args.target[6:8], L, args.replicas, args.seqs,
+                                      "in total, replica r on GPU r mod N" if strong else "per GPU"),
+                       "replicas_per_gpu": R if not strong else None, "replicas_total": R_total,
+                       "replicas_on_rank0": R, "L": L, "exchange_every": args.exchange_every,
+                       "threads_per_workgroup": eng.info()["threads_per_wg"],
+                       "launches_per_step": 1 if fused else 2},
             "kernel_ms": {k: round(v, 4) for k, v in tk.items()},
-            "roofline": roofline_block(dom, tk[dom], L, R, tk),
+            "roofline": roofline_block(dom, tk[dom], L, R, tk, fused),
         }
-        hb = (out["roofline"].get("bounds") or {}).get("hbm")
-        out["achieved_hbm_GB_s"] = hb["achieved"] if hb else None          # BASELINE metric: "HBM GB/s vs peak" (8000)
+        rb = out["roofline"]
+        hb = (rb.get("bounds") or {}).get("hbm")
+        out["achieved_hbm_GB_s"] = hb["achieved"] if hb else None          # BASELINE metric: "HBM GB/s vs peak" (8000): both folds of a step
         out["achieved_hbm_frac_of_peak"] = hb["frac"] if hb else None
         out["sync_fallbacks"] = eng.get_option("sync_fallbacks")          # calls redone with one workgroup per fold (lost partner)
-        out["cus_occupied"] = {"workgroups": eng.get_option("last_workgroups"), "compute_units": eng.info()["compute_units"]}
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would idle at the barrier
+        out["cus_occupied"] = {"workgroups": eng.get_option("last_workgroups"), "compute_units": eng.info()["compute_units"],
+                               "resident_check": ("grid %d <= %d blocks/CU x %d CUs (occupancy query)"
+                                                  % (eng.get_option("last_workgroups"), eng.get_option("fused_blocks_per_cu"), eng.info()["compute_units"])) if fused else None}
+        if per_rank is not None:
+            out["ranks"] = {"ms_per_step_min": float(per_rank[:, 0].min()), "ms_per_step_max": float(per_rank[:, 0].max()),
+                            "allgather_us_mean": float(per_rank[:, 1].mean()), "allgather_us_max": float(per_rank[:, 1].max()),
+                            "allgather_calls": gather_s[1], "allgather_bytes_per_rank": 8 * R_max,
+                            "note": "ms_per_step: every rank's own clock over the timed steps, before the closing barrier; "
+                                    "allgather_us: wall time of the exchange step's collective incl. staging the scores"}
+        if strong:
+            out["strong_scaling_note"] = ("a step is one chain of %d diagonals per fold whatever the batch (%.3f ms of kernel time with %d "
+                                          "replicas on this GPU, chain-bound: SURVEY 8(d), DESIGN 3.9), so with R = %d in TOTAL ms_per_step "
+                                          "stays flat as N grows and value does not scale; the weak mode (R per GPU) is the throughput mode"
+                                          % (L - 4, tk["total"], R, args.replicas))
+        ref = None
+        if not args.no_cpu_baseline and world == 1:      # the timed CPU baseline on rank 0 at N=1 only: at N>1 the other ranks would idle at the barrier
             out["cpu_baseline"], ref = cpu_baseline(seqs, target)
             out["speedup_vs_cpu_usable_cores"] = out["value"] / world / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_reference_style_R_processes"] = out["value"] / world / out["cpu_baseline"]["reference_style_R_processes"]["value"]
+        elif not args.no_cpu_baseline:
+            ref = oracle_reference(seqs, target)          # N > 1: rank 0's shard against the oracle (tens of ms of CPU), no timing
+        if ref is not None:
             # what the timed steps left in the device buffers against the oracle's answers for the same batch:
             # MFE energy, MFE structure and E(target) bit for bit, Epf to 1e-9 kcal/mol
             r_Epf, r_Emfe, r_ss, r_Ed = ref
@@ -395,10 +575,15 @@ def main():
                   and float(np.abs(d_Epf.cpu().numpy() - r_Epf).max()) < 1e-9)
             out["parity_checked"] = bool(ok)
             out["parity"] = {"sequences": R, "max_abs_dEpf": float(np.abs(d_Epf.cpu().numpy() - r_Epf).max()),
-                             "Emfe_Ed_structures": "bit-exact" if ok else "MISMATCH"}
+                             "Emfe_Ed_structures": "bit-exact" if ok else "MISMATCH",
+                             "of": "rank 0's shard" if world > 1 else "the whole batch"}
             if not ok:
                 print(json.dumps(out))
                 raise SystemExit("bench: GPU results differ from the oracle")
+        if not args.no_mc_loop and not shared_card:
+            out["mc_loop"] = mc_loop_block(eng, target, R, args.exchange_every, out["value"] / world, tk["total"])
+        if args.r_sweep and world == 1:
+            out["r_sweep"] = r_sweep_block(target, local_rank)
         print(json.dumps(out))
     if multi:
         dist.barrier()

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <numeric>
 #include <string>
@@ -20,6 +21,7 @@
 #include "fold_cofold.hpp"
 #include "fold_mfe_lds.hpp"
 #include "fold_mfe_dual.hpp"
+#include "fold_fused.hpp"
 #include "fold_mfe_strip.hpp"
 #include "fold_outside.hpp"
 #include "fold_pf.hpp"
@@ -113,6 +115,11 @@ struct drna_engine {
                                   // partition function (fold_pf_lds.hpp, pf_kfar_helper); option "pf_helper"
   int* d_pflags = nullptr;        // its hand-over flags: per sequence two 128-byte lines
   int pflags_cap = 0, pfh_epoch = 0;
+  bool fused = true;              // small batches: both folds in ONE launch of 4 R workgroups (fold_fused.hpp); option "fused", DRNA_FUSED=0
+  int fused_blocks_per_cu = -1;   // occupancy query of the fused kernel (-1: not asked yet)
+  long long *h_clk = nullptr, *d_clk = nullptr;   // host-mapped: start / end wall clock of every block of the fused launch
+  int clk_cap = 0;
+  bool last_fused = false;        // the last drna_score_batch_device call went through the fused launch
   int last_wgs = 0;               // fold workgroups of the last drna_score_batch call (partition function + MFE kernels, resident side by side)
   int sync_fallbacks = 0;         // calls that lost a multi-workgroup fold (ST_SYNC) and were redone with one workgroup per fold
   // A GPU shared with another process (or a runtime that stops dispatching in block order) loses partners call after call, and
@@ -120,6 +127,8 @@ struct drna_engine {
   // for the next SOLO_CALLS calls (option "solo_calls_left"); then one call probes again.  Any set_option of the paths resets it.
   int fallback_streak = 0, solo_left = 0;
   bool in_fallback = false;
+  int mc_threads_used = 0;        // worker threads (the caller included) of the last drna_mc_run
+  int mc_threads = 0;             // option "mc_threads" / DRNA_MC_THREADS: worker threads of drna_mc_run's host work (0 = min(8, usable CPUs / 2))
   int* d_sflags = nullptr;        // [2: partition function, MFE][max_R][STRIP_MAXS][32]
   int32_t* d_srec = nullptr;      // MFE strips: exchange records and list counts, srec_stride int32 per sequence
   long long srec_stride = 0;
@@ -263,8 +272,10 @@ static int create_impl(drna_engine* e, const int32_t* params, int n_int32, int d
   e->cus = prop.multiProcessorCount;
   if (const char* dv = getenv("DRNA_DUAL")) { e->dual = atoi(dv) != 0; e->dual_force = atoi(dv) == 2; }
   if (const char* hv = getenv("DRNA_PF_HELPER")) e->pf_helper = atoi(hv) != 0;
+  if (const char* fv = getenv("DRNA_FUSED")) e->fused = atoi(fv) != 0;
   if (const char* mv = getenv("DRNA_MFE_SPLIT")) { const int v = atoi(mv); e->mfe_split = v < 1 ? 1 : v > 8 ? 8 : v; }
   if (const char* fv = getenv("DRNA_MFE_FARK_MIN_STRIPS")) { const int v = atoi(fv); e->mfe_fark_min_strips = v < 1 ? 1 : v; }
+  if (const char* tv = getenv("DRNA_MC_THREADS")) { const int v = atoi(tv); e->mc_threads = v < 0 ? 0 : v > 64 ? 64 : v; }
   if (const char* sv = getenv("DRNA_STRIPS")) { const int v = atoi(sv); e->strips = v < 0 ? 0 : v > 2 ? 2 : v; }
   HIP_TRY(upload(&e->d_mfeT, &e->H.mfe, 1));
   HIP_TRY(upload(&e->d_pfT, &e->H.pf, 1));
@@ -338,7 +349,7 @@ extern "C" void drna_destroy(drna_engine* e) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->h_status) (void)hipHostFree(e->h_status);
-  void* hm[] = {e->hm_seqs, e->hm_ss, e->hm_Epf, e->hm_Emfe, e->hm_Ed};
+  void* hm[] = {e->hm_seqs, e->hm_ss, e->hm_Epf, e->hm_Emfe, e->hm_Ed, e->h_clk};
   for (void* b : hm)
     if (b) (void)hipHostFree(b);
   hipStream_t ss[] = {e->s_mfe, e->s_pf, e->s_eval};
@@ -356,13 +367,15 @@ extern "C" int drna_abi_version(void) { return DRNA_ABI_VERSION; }
 
 extern "C" int drna_set_option(drna_engine* e, const char* name, int value) {
   if (!e || !name) return DRNA_ERR_ARG;
-  if (!strcmp(name, "dual") || !strcmp(name, "strips") || !strcmp(name, "pf_helper")) { e->fallback_streak = 0; e->solo_left = 0; }
+  if (!strcmp(name, "dual") || !strcmp(name, "strips") || !strcmp(name, "pf_helper") || !strcmp(name, "fused")) { e->fallback_streak = 0; e->solo_left = 0; }
+  if (!strcmp(name, "fused")) { e->fused = value != 0; return DRNA_OK; }
   if (!strcmp(name, "dual")) { e->dual = value != 0; e->dual_force = value == 2; return DRNA_OK; }
   if (!strcmp(name, "strips")) { e->strips = value < 0 ? 0 : value > 2 ? 2 : value; return DRNA_OK; }
   if (!strcmp(name, "pf_helper")) { e->pf_helper = value != 0; return DRNA_OK; }
   if (!strcmp(name, "helper_fault")) { e->helper_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "strip_fault")) { e->strip_fault = value != 0; return DRNA_OK; }
   if (!strcmp(name, "mfe_fark_min_strips")) { e->mfe_fark_min_strips = value < 1 ? 1 : value; return DRNA_OK; }
+  if (!strcmp(name, "mc_threads")) { e->mc_threads = value < 0 ? 0 : value > 64 ? 64 : value; return DRNA_OK; }
   if (!strcmp(name, "mfe_split")) { e->mfe_split = value < 1 ? 1 : value > 8 ? 8 : value; return DRNA_OK; }
   if (!strcmp(name, "debug_epoch")) { e->strip_epoch = value; e->dual_epoch = value; e->pfh_epoch = value; return DRNA_OK; }     // tests: jump near the reset point
   e->err = std::string("drna_set_option: unknown option ") + name;
@@ -383,9 +396,14 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!strcmp(name, "dual")) { *value = e->dual ? (e->dual_force ? 2 : 1) : 0; return DRNA_OK; }
   if (!strcmp(name, "strips")) { *value = e->strips; return DRNA_OK; }
   if (!strcmp(name, "pf_helper")) { *value = e->pf_helper ? 1 : 0; return DRNA_OK; }
+  if (!strcmp(name, "fused")) { *value = e->fused ? 1 : 0; return DRNA_OK; }
+  if (!strcmp(name, "last_fused")) { *value = e->last_fused ? 1 : 0; return DRNA_OK; }
+  if (!strcmp(name, "fused_blocks_per_cu")) { *value = e->fused_blocks_per_cu; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
   if (!strcmp(name, "solo_calls_left")) { *value = e->solo_left; return DRNA_OK; }
   if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
+  if (!strcmp(name, "mc_threads")) { *value = e->mc_threads; return DRNA_OK; }
+  if (!strcmp(name, "mc_threads_used")) { *value = e->mc_threads_used; return DRNA_OK; }
   if (!strcmp(name, "workspace_slots")) { *value = e->ws_slots; return DRNA_OK; }
   if (!strcmp(name, "flag_resets")) { *value = e->flag_resets; return DRNA_OK; }
   if (!strcmp(name, "debug_epoch")) { *value = std::max(e->pfh_epoch, std::max(e->strip_epoch, e->dual_epoch)); return DRNA_OK; }
@@ -434,6 +452,17 @@ static void launch_mfe(const MfeArgs& a, int R, hipStream_t s) {
 template <int NT>
 static void launch_pf(const PfArgs& a, int R, hipStream_t s) {
   hipLaunchKernelGGL(pf_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+
+// The fused launch's workgroups wait for each other, so the whole grid must be resident at once: the grid is checked against
+// the occupancy query (what hipLaunchCooperativeKernel would check, without its ~17 us per launch)
+static bool fused_grid_fits(drna_engine* e, int R) {
+  if (e->fused_blocks_per_cu < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, score_fused_kernel<1024>, 1024, 0) != hipSuccess) nb = 0;
+    e->fused_blocks_per_cu = nb;
+  }
+  return (long long)fused_grid(R) <= (long long)e->fused_blocks_per_cu * e->cus;
 }
 
 extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char* d_seqs, uint32_t flags, double* d_Epf,
@@ -555,20 +584,24 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   int pf_gate_round = -1;
   static const int pf_gate_part = getenv("DRNA_PF_GATE_PART") ? atoi(getenv("DRNA_PF_GATE_PART")) : 0;
   bool pf_gated = false;
-  auto enqueue_pf = [&]() -> int {
+  auto make_pf_args = [&]() {
     PfArgs a;
     a.T = e->d_pfT; a.plan = e->d_plan; a.hp_w = e->d_hp_w; a.scale = e->d_scale; a.eMLb = e->d_eMLb;
     a.seqs = d_seqs; a.L = L; a.ld = ld;
     a.ws = e->d_ws_pf; a.ws_stride = (long long)pf_ws_stride(ld);
     a.Epf = d_Epf; a.status = e->d_status + e->max_R;
+    if (pf_help) { a.helper = e->helper_fault ? 2 : 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12); }
+    return a;
+  };
+  auto enqueue_pf = [&]() -> int {
+    PfArgs a = make_pf_args();
     if (pf_gated) HIP_TRY(hipStreamWaitEvent(e->s_pf, e->ev_gate, 0));
     HIP_TRY(hipEventRecord(e->ev_p0, e->s_pf));
     e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
-    else if (pf_help) {
-      a.helper = e->helper_fault ? 2 : 1; a.hflags = e->d_pflags; a.hbase = (int)((unsigned)e->pfh_epoch << 12);
+    else if (pf_help)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
-    } else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
+    else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{});
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
@@ -577,18 +610,26 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     HIP_TRY(hipEventRecord(e->ev_p1, e->s_pf));
     return DRNA_OK;
   };
-  auto enqueue_mfe = [&]() -> int {
+  auto make_mfe_args = [&]() {
     MfeArgs a;
     a.T = e->d_mfeT; a.plan = e->d_plan; a.hp_len = e->d_hp_len; a.seqs = d_seqs; a.L = L; a.ld = ld;
     a.pk_rounds = want_pk ? 3 : 0;
     a.ws = e->d_ws_mfe; a.ws_stride = (long long)mfe_ws_stride(ld);
     a.Emfe = d_Emfe; a.ss = d_mfe_ss; a.status = e->d_status;
+    return a;
+  };
+  auto make_dual_link = [&]() {
+    DualLink lk;
+    lk.flagA = e->d_dflags; lk.flagB = e->d_dflags;
+    lk.xs = e->d_xs; lk.xa = e->d_xa_mfe; lk.xb = e->d_xb_mfe; lk.epoch = e->dual_epoch;
+    return lk;
+  };
+  auto enqueue_mfe = [&]() -> int {
+    MfeArgs a = make_mfe_args();
     HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
     e->last_wgs += use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R;
     if (use_dual) {
-      DualLink lk;
-      lk.flagA = e->d_dflags; lk.flagB = e->d_dflags;
-      lk.xs = e->d_xs; lk.xa = e->d_xa_mfe; lk.xb = e->d_xb_mfe; lk.epoch = e->dual_epoch;
+      DualLink lk = make_dual_link();
 #ifdef DRNA_DUALDBG
       lk.dbg = reinterpret_cast<long long*>(e->d_ws_mfe + 2 * (size_t)ld * ld + 8192);  // table 2 of sequence 0's workspace is unused by the LDS kernels
       (void)hipMemsetAsync(lk.dbg, 0, 64 * 64 * sizeof(long long), e->s_mfe);
@@ -619,6 +660,45 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
     return DRNA_OK;
   };
+  // ---- small batches (the headline shape): both folds in ONE launch, 4 R workgroups resident side by side (fold_fused.hpp)
+  e->last_fused = false;
+  const bool use_fused = e->fused && use_dual && pf_help && want_mfe && want_pf && (!want_ev || ev_in_pf) && fused_grid_fits(e, R);
+  if (use_fused) {
+    const int grid = fused_grid(R);
+    if (e->clk_cap < grid) {
+      if (e->h_clk) (void)hipHostFree(e->h_clk);
+      e->h_clk = nullptr; e->clk_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&e->h_clk, (size_t)2 * grid * sizeof(long long), hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer((void**)&e->d_clk, e->h_clk, 0));
+      e->clk_cap = grid;
+    }
+    HIP_TRY(hipEventRecord(e->ev_m0, e->s_mfe));
+    hipLaunchKernelGGL(score_fused_kernel<1024>, dim3(grid), dim3(1024), 0, e->s_mfe, make_mfe_args(), make_dual_link(), make_pf_args(),
+                       want_ev ? make_eval_args() : EvalArgs{}, R, e->d_clk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_m1, e->s_mfe));
+    e->last_wgs = 4 * R;
+    e->last_fused = true;
+    HIP_TRY(hipStreamSynchronize(e->s_mfe));
+    float tot = 0.f;
+    HIP_TRY(hipEventElapsedTime(&tot, e->ev_m0, e->ev_m1));
+    // per-fold times from the blocks' own clocks (100 MHz): first start of any block to the last end of the fold's blocks
+    long long t0 = 0, end_mfe = 0, end_pf = 0;
+    bool first = true;
+    for (int b = 0; b < grid; b++) {
+      int r, role;
+      fused_block_role(b, r, role);
+      if (r >= R) continue;
+      const long long s0 = e->h_clk[2 * b], s1 = e->h_clk[2 * b + 1];
+      if (first || s0 < t0) t0 = s0;
+      first = false;
+      if (role <= ROLE_MFE_HELPER) { if (s1 > end_mfe) end_mfe = s1; } else if (s1 > end_pf) end_pf = s1;
+    }
+    e->timing[0] = (float)((end_mfe - t0) * 1e-5); e->timing[1] = (float)((end_pf - t0) * 1e-5);
+    e->timing[2] = 0.f; e->timing[3] = tot;
+    for (int k = 0; k < 4; k++) e->timing_sum[k] += e->timing[k];
+    e->timing_sum[4] += 1.0;
+  }
   const bool mfe_first = want_mfe && (!want_pf || e->timing[0] > e->timing[1]);
   // the evaluation kernel (~20 us) rides in FRONT of the shorter fold on that fold's stream: one stream less to drain at the end
   hipStream_t s_ev = e->s_eval;
@@ -632,6 +712,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     HIP_TRY(hipEventRecord(e->ev_e1, s_ev));
     return DRNA_OK;
   };
+  if (!use_fused) {
   if (mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
   if (want_ev && s_ev == e->s_pf) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
   if (want_pf) { const int rc = enqueue_pf(); if (rc != DRNA_OK) return rc; }
@@ -667,6 +748,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     for (int k = 0; k < 4; k++) e->timing_sum[k] += e->timing[k];
     e->timing_sum[4] += 1.0;
   }
+  }   // !use_fused
   for (int r = 0; r < R; r++) {
     const int sm = want_mfe ? e->h_status[r] : ST_OK, sp = want_pf ? e->h_status[e->max_R + r] : ST_OK;
     const int st = sm != ST_OK ? sm : sp;
@@ -795,12 +877,21 @@ extern "C" int drna_ensemble_defect_batch_device(drna_engine* e, int R, int L, c
     e->err = "drna_ensemble_defect_batch: needs drna_set_targets() with the same L (targets[0] is the reference structure)";
     return DRNA_ERR_ARG;
   }
-  if (R > e->ws_slots) { e->err = "drna_ensemble_defect_batch: batch larger than the workspace (raise DRNA_WS_GB or split the batch)"; return DRNA_ERR_ARG; }
+  if (R > e->ws_slots) {
+    // more sequences than the workspaces hold (DRNA_WS_GB): one sub-batch of ws_slots after the other, as drna_score_batch_device does
+    for (int r0 = 0; r0 < R; r0 += e->ws_slots) {
+      const int m = std::min(e->ws_slots, R - r0);
+      const int rc = drna_ensemble_defect_batch_device(e, m, L, d_seqs + (size_t)r0 * L, d_edef + r0,
+                                                       d_bpp ? d_bpp + (size_t)r0 * (L + 1) * (L + 1) : nullptr);
+      if (rc != DRNA_OK) return rc;
+    }
+    return DRNA_OK;
+  }
   HIP_TRY(hipSetDevice(e->device));
   const int ldmax = e->max_L + 2, ld = L + 2;
   if (!e->d_ws_out) {
-    HIP_TRY(hipMalloc((void**)&e->d_ws_out, (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->max_R));
-    e->ws_bytes += (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->max_R;
+    HIP_TRY(hipMalloc((void**)&e->d_ws_out, (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->ws_slots));
+    e->ws_bytes += (size_t)outside_ws_stride(ldmax) * sizeof(double) * e->ws_slots;
   }
   for (int k = 0; k < R; k++) e->h_status[e->max_R + k] = ST_OK;
   // the general inside kernel: it leaves qb / qm / qm1 in the workspace (the LDS kernel keeps only rings)
@@ -1347,21 +1438,8 @@ extern "C" int drna_simscore_batch(int R, int L, const char* ref, const char* qu
   if (!pair_table(ref, L, pr.data())) return DRNA_ERR_STRUCTURE;
   for (int r = 0; r < R; r++) {
     if (!pair_table(queries + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
-    long tp = 0, fp = 0, fn = 0, tn = 0;
-    for (int i = 0; i < L; i++) {
-      if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }
-      else if (pr[i] == -1) fp++;
-      else fn++;
-    }
-    double num, den;
-    if (tp == 0 && fp == 0 && fn == 0 && tn != 0) { num = 1; den = 1; }
-    else {
-      num = (double)(tp * tn) - (double)(fp * fn);
-      den = std::sqrt((double)((tp + fp) * (tp + fn) * (tn + fn) * (tn + fp)));
-    }
-    mcc[r] = py_round3(num / (den + 0.00001));
-    recall[r] = py_round3((double)tp / ((double)(tp + fn) + 0.001));
-    precision[r] = py_round3((double)tp / ((double)(tp + fp) + 0.001));
+    const SimMetrics m = sim_metrics(pr.data(), pq.data(), L);
+    mcc[r] = m.mcc; recall[r] = m.recall; precision[r] = m.precision;
   }
   return DRNA_OK;
 }
@@ -1378,95 +1456,139 @@ extern "C" int drna_rng_random(int R, uint32_t* rng_state, double* out) {
   return DRNA_OK;
 }
 
-// one proposal per replica; pt_design = partner of every design pair (target + ordinary alternative pairs), snakes optional
+// The design problem as the proposer sees it, built once per call (drna_propose_batch*) or per exchange step (drna_mc_run):
+// pair tables of the target and of all design pairs, the mutable positions, the snakes of alternative-structure designs
+struct ProposeCtx {
+  int L = 0, n_shelves = 1, targeted = 0;
+  double tm_max = 0, tm_min = 0;
+  const unsigned char* allowed_mask = nullptr;
+  const int32_t *snake_of = nullptr, *snake_off = nullptr, *snake_nodes = nullptr, *snake_nstates = nullptr;
+  const char* snake_states = nullptr;
+  std::vector<int> pt, pd, mutable_pos;
+};
+static int propose_ctx_init(ProposeCtx& c, int L, const char* target, const int32_t* partner, const unsigned char* allowed_mask,
+                            const int32_t* snake_of, const int32_t* snake_off, const int32_t* snake_nodes,
+                            const int32_t* snake_nstates, const char* snake_states, int n_shelves, double tm_max, double tm_min,
+                            int targeted) {
+  using namespace drna_host;
+  c.L = L; c.n_shelves = n_shelves; c.targeted = targeted; c.tm_max = tm_max; c.tm_min = tm_min; c.allowed_mask = allowed_mask;
+  c.snake_of = snake_of; c.snake_off = snake_off; c.snake_nodes = snake_nodes; c.snake_nstates = snake_nstates; c.snake_states = snake_states;
+  c.pt.assign(L, -1); c.pd.assign(L, -1); c.mutable_pos.clear();
+  if (!pair_table(target, L, c.pt.data())) return DRNA_ERR_STRUCTURE;
+  for (int i = 0; i < L; i++) {
+    c.pd[i] = partner ? partner[i] : c.pt[i];
+    if (c.pd[i] >= L || (c.pd[i] >= 0 && (partner ? partner[c.pd[i]] : c.pt[c.pd[i]]) != i)) return DRNA_ERR_ARG;
+  }
+  for (int i = 0; i < L; i++)
+    if (__builtin_popcount(allowed_mask[i] & 15u) != 1) c.mutable_pos.push_back(i);
+  if (c.mutable_pos.empty()) return DRNA_ERR_ARG;
+  return DRNA_OK;
+}
+// round(numpy.linspace(tm_max, tm_min, n_shelves)[shelf], 2): linspace is start + k * step with the last point set to the stop
+// value; round() is the correctly rounded decimal, like printf
+static double shelf_probability(const ProposeCtx& c, int shelf) {
+  double p = c.tm_max;
+  if (c.n_shelves > 1) {
+    const double step = (c.tm_min - c.tm_max) / (double)(c.n_shelves - 1);
+    p = shelf == c.n_shelves - 1 ? c.tm_min : (double)shelf * step + c.tm_max;
+  }
+  char buf[32]; snprintf(buf, sizeof buf, "%.2f", p);
+  return strtod(buf, nullptr);
+}
+// targeted moves: the positions a proposal may pick from = ends of false-negative / false-positive pairs of the current MFE
+// structure (pair table pq) against the target, widened by +-3 (position 0 never enters); returns their number (0: none).
+// mark is scratch of L entries.  The pool depends on the replica's CURRENT structure only, so drna_mc_run keeps it until a
+// proposal is accepted
+static int targeted_pool(const ProposeCtx& c, const int* pq, char* mark, int* pool) {
+  const int L = c.L;
+  std::memset(mark, 0, (size_t)L);
+  bool any = false;
+  for (int i = 0; i < L; i++)
+    if (c.pt[i] != pq[i] && (c.pt[i] >= 0 || pq[i] >= 0) && __builtin_popcount(c.allowed_mask[i] & 15u) != 1) {
+      any = true;                                       // end of a false-negative or false-positive pair
+      for (int k = -3; k <= 3; k++) { const int x = i + k; if (x > 0 && x <= L - 1) mark[x] = 1; }
+    }
+  int np = 0;
+  if (any)
+    for (int i = 0; i < L; i++) if (mark[i]) pool[np++] = i;
+  return any ? np : -1;                                  // -1: no mispaired position (no draw is made then)
+}
+// one proposal of one replica: s = its sequence, pool / np = targeted_pool of its current MFE structure (np = -1 without targeted
+// moves), p_shelf = shelf_probability of its temperature shelf
+static int propose_one(const ProposeCtx& c, const char* s, const int* pool, int np, double p_shelf, drna_host::Mt st, char* o) {
+  using namespace drna_host;
+  static const char LET[4] = {'A', 'C', 'G', 'U'};
+  static const unsigned CANPAIR[4] = {8u, 4u, 2u | 8u, 1u | 4u};   // A-U, C-G, G-C/U, U-A/G
+  const int L = c.L;
+  const unsigned char* allowed_mask = c.allowed_mask;
+  auto letter_index = [](char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3; };
+  std::memcpy(o, s, (size_t)L);
+  int pos = -1;
+  if (np >= 0 && rnd_choices2(st, p_shelf) == 0 && np > 0)          // choices([expanded, mutable], weights=[p, 1 - p])
+    pos = pool[rnd_below(st, np)];
+  if (pos < 0) pos = c.mutable_pos[rnd_below(st, (int)c.mutable_pos.size())];
+  const unsigned am = allowed_mask[pos] & 15u;
+  const int cur = letter_index(s[pos]);
+  const int j = c.pd[pos];
+  if (c.snake_of && c.snake_of[pos] >= 0) {
+    // alternative structures: the whole connected component moves to another of its Watson-Crick colourings
+    // (reference utils/sequence_utils.py:1081-1095)
+    const int k = c.snake_of[pos], n0 = c.snake_off[k], len = c.snake_off[k + 1] - n0, ns = c.snake_nstates[k];
+    const char* states = c.snake_states + (size_t)4 * n0;
+    int x = 0;
+    while (x < len && c.snake_nodes[n0 + x] != pos) x++;
+    if (x == len) return DRNA_ERR_ARG;
+    int curst = -1;
+    for (int q = 0; q < ns; q++) if (states[(size_t)q * len + x] == s[pos]) { curst = q; break; }
+    const int nopt = ns - (curst >= 0 ? 1 : 0);
+    if (nopt > 0) {
+      int pick = rnd_below(st, nopt);
+      if (curst >= 0 && pick >= curst) pick++;
+      for (int y = 0; y < len; y++) o[c.snake_nodes[n0 + y]] = states[(size_t)pick * len + y];
+    }
+  } else if (j < 0) {
+    unsigned opts = __builtin_popcount(am) > 1 ? (am & ~(1u << cur)) : 0u;
+    if (opts) {
+      int k = rnd_below(st, __builtin_popcount(opts));
+      for (int b = 0; b < 4; b++) if (opts & (1u << b)) { if (!k--) { o[pos] = LET[b]; break; } }
+    }
+  } else {
+    unsigned o1 = __builtin_popcount(am) != 1 ? (am & ~(1u << cur)) : am;
+    if (!o1) o1 = am;
+    int k = rnd_below(st, __builtin_popcount(o1));
+    int n1 = 0;
+    for (int b = 0; b < 4; b++) if (o1 & (1u << b)) { if (!k--) { n1 = b; break; } }
+    const unsigned o2 = (allowed_mask[j] & 15u) & CANPAIR[n1];
+    if (o2) {
+      int k2 = rnd_below(st, __builtin_popcount(o2));
+      for (int b = 0; b < 4; b++) if (o2 & (1u << b)) { if (!k2--) { o[pos] = LET[n1]; o[j] = LET[b]; break; } }
+    }
+  }
+  return DRNA_OK;
+}
+
+// one proposal per replica; partner = partner of every design pair (target + ordinary alternative pairs), snakes optional
 static int propose_impl(int R, int L, const char* target, const int32_t* partner, const unsigned char* allowed_mask,
                         const int32_t* snake_of, const int32_t* snake_off, const int32_t* snake_nodes,
                         const int32_t* snake_nstates, const char* snake_states, const char* seqs, const char* mfe_ss,
                         const int32_t* shelf_index, int n_shelves, double tm_max, double tm_min, int targeted,
                         uint32_t* rng_state, char* out_seqs) {
   using namespace drna_host;
-  static const char LET[4] = {'A', 'C', 'G', 'U'};
-  static const unsigned CANPAIR[4] = {8u, 4u, 2u | 8u, 1u | 4u};   // A-U, C-G, G-C/U, U-A/G
-  std::vector<int> pt(L), pd(L), pq(L), mutable_pos, pool;
+  ProposeCtx c;
+  int rc = propose_ctx_init(c, L, target, partner, allowed_mask, snake_of, snake_off, snake_nodes, snake_nstates, snake_states,
+                            n_shelves, tm_max, tm_min, targeted);
+  if (rc != DRNA_OK) return rc;
+  std::vector<int> pq(L), pool(L);
   std::vector<char> mark(L);
-  if (!pair_table(target, L, pt.data())) return DRNA_ERR_STRUCTURE;
-  for (int i = 0; i < L; i++) {
-    pd[i] = partner ? partner[i] : pt[i];
-    if (pd[i] >= L || (pd[i] >= 0 && (partner ? partner[pd[i]] : pt[pd[i]]) != i)) return DRNA_ERR_ARG;
-  }
-  for (int i = 0; i < L; i++)
-    if (__builtin_popcount(allowed_mask[i] & 15u) != 1) mutable_pos.push_back(i);
-  if (mutable_pos.empty()) return DRNA_ERR_ARG;
-  auto letter_index = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
   for (int r = 0; r < R; r++) {
-    const Mt st{rng_state + (size_t)r * RNG_WORDS};
-    const char* s = seqs + (size_t)r * L;
-    char* o = out_seqs + (size_t)r * L;
-    std::memcpy(o, s, (size_t)L);
-    int pos = -1;
+    int np = -1;
     if (targeted) {
       if (!pair_table(mfe_ss + (size_t)r * L, L, pq.data())) return DRNA_ERR_STRUCTURE;
-      std::fill(mark.begin(), mark.end(), 0);
-      bool any = false;
-      for (int i = 0; i < L; i++)
-        if (pt[i] != pq[i] && (pt[i] >= 0 || pq[i] >= 0) && __builtin_popcount(allowed_mask[i] & 15u) != 1) {
-          any = true;                                       // end of a false-negative or false-positive pair
-          for (int k = -3; k <= 3; k++) { const int x = i + k; if (x > 0 && x <= L - 1) mark[x] = 1; }
-        }
-      if (any) {
-        // round(numpy.linspace(tm_max, tm_min, n_shelves)[shelf], 2): linspace is start + k * step with the last point
-        // set to the stop value; round() is the correctly rounded decimal, like printf
-        double p = tm_max;
-        if (n_shelves > 1) {
-          const double step = (tm_min - tm_max) / (double)(n_shelves - 1);
-          p = shelf_index[r] == n_shelves - 1 ? tm_min : (double)shelf_index[r] * step + tm_max;
-        }
-        char buf[32]; snprintf(buf, sizeof buf, "%.2f", p); p = strtod(buf, nullptr);
-        if (rnd_choices2(st, p) == 0) {                      // choices([expanded, mutable], weights=[p, 1 - p])
-          pool.clear();
-          for (int i = 0; i < L; i++) if (mark[i]) pool.push_back(i);
-          pos = pool[rnd_below(st, (int)pool.size())];
-        }
-      }
+      np = targeted_pool(c, pq.data(), mark.data(), pool.data());
     }
-    if (pos < 0) pos = mutable_pos[rnd_below(st, (int)mutable_pos.size())];
-    const unsigned am = allowed_mask[pos] & 15u;
-    const int cur = letter_index(s[pos]);
-    const int j = pd[pos];
-    if (snake_of && snake_of[pos] >= 0) {
-      // alternative structures: the whole connected component moves to another of its Watson-Crick colourings
-      // (reference utils/sequence_utils.py:1081-1095)
-      const int k = snake_of[pos], n0 = snake_off[k], len = snake_off[k + 1] - n0, ns = snake_nstates[k];
-      const char* states = snake_states + (size_t)4 * n0;
-      int x = 0;
-      while (x < len && snake_nodes[n0 + x] != pos) x++;
-      if (x == len) return DRNA_ERR_ARG;
-      int curst = -1;
-      for (int q = 0; q < ns; q++) if (states[(size_t)q * len + x] == s[pos]) { curst = q; break; }
-      const int nopt = ns - (curst >= 0 ? 1 : 0);
-      if (nopt > 0) {
-        int pick = rnd_below(st, nopt);
-        if (curst >= 0 && pick >= curst) pick++;
-        for (int y = 0; y < len; y++) o[snake_nodes[n0 + y]] = states[(size_t)pick * len + y];
-      }
-    } else if (j < 0) {
-      unsigned opts = __builtin_popcount(am) > 1 ? (am & ~(1u << cur)) : 0u;
-      if (opts) {
-        int k = rnd_below(st, __builtin_popcount(opts));
-        for (int b = 0; b < 4; b++) if (opts & (1u << b)) { if (!k--) { o[pos] = LET[b]; break; } }
-      }
-    } else {
-      unsigned o1 = __builtin_popcount(am) != 1 ? (am & ~(1u << cur)) : am;
-      if (!o1) o1 = am;
-      int k = rnd_below(st, __builtin_popcount(o1));
-      int n1 = 0;
-      for (int b = 0; b < 4; b++) if (o1 & (1u << b)) { if (!k--) { n1 = b; break; } }
-      const unsigned o2 = (allowed_mask[j] & 15u) & CANPAIR[n1];
-      if (o2) {
-        int k2 = rnd_below(st, __builtin_popcount(o2));
-        for (int b = 0; b < 4; b++) if (o2 & (1u << b)) { if (!k2--) { o[pos] = LET[n1]; o[j] = LET[b]; break; } }
-      }
-    }
+    rc = propose_one(c, seqs + (size_t)r * L, pool.data(), np, targeted ? shelf_probability(c, shelf_index[r]) : 0.0,
+                     Mt{rng_state + (size_t)r * RNG_WORDS}, out_seqs + (size_t)r * L);
+    if (rc != DRNA_OK) return rc;
   }
   return DRNA_OK;
 }
@@ -1534,75 +1656,124 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
   }
   const int nt = e->n_targets;
   std::vector<char> prop((size_t)R * L), pss((size_t)R * L);
-  std::vector<double> pEpf(R), pscore(R), pmcc(R), prec(R), pprec(R), pEdef;
+  std::vector<double> pEpf(R), pscore(R), pmcc(R), pEdef, p_shelf(R, 0.0);
   bool want_edef = false;                  // term 6: ensemble defect against targets[0] (utils/energy_scores.py:362-374,397-398)
-  for (int k = 0; k < n_terms; k++) want_edef |= term_id[k] == 6;
+  for (int k = 0; k < n_terms; k++) {
+    want_edef |= term_id[k] == 6;
+    if (term_id[k] < 0 || term_id[k] > 6) { e->err = "drna_mc_run: unknown scoring term"; return DRNA_ERR_ARG; }
+  }
   if (want_edef) pEdef.resize(R);
   std::vector<int32_t> pEmfe(R), pEd((size_t)R * nt);
   std::vector<unsigned char> acc(R), better(R);
-  std::vector<int> pr(L), pq(L);
-  if (!pair_table(target, L, pr.data())) { e->err = "drna_mc_run: unbalanced target structure"; return DRNA_ERR_STRUCTURE; }
+  ProposeCtx ctx;
+  {
+    const int rc = propose_ctx_init(ctx, L, target, partner, allowed_mask, n_snakes > 0 ? snake_of : nullptr, snake_off, snake_nodes,
+                                    snake_nstates, snake_states, n_shelves, tm_max, tm_min, targeted);
+    if (rc != DRNA_OK) { e->err = rc == DRNA_ERR_STRUCTURE ? "drna_mc_run: unbalanced target structure" : "drna_mc_run: proposal failed"; return rc; }
+  }
+  const int* pr = ctx.pt.data();
+  // Per replica, of its CURRENT structure: the pair table, its SimScore against the target and the targeted-move pool (what the
+  // proposal compares with the target).  Parsed once here and replaced when a proposal is accepted; a proposal whose MFE
+  // structure equals the current one (most single mutations of a converged replica) reuses all three
+  std::vector<int> cur_pq((size_t)R * L), prop_pq((size_t)R * L), cur_pool((size_t)R * L), cur_np(R, -1);
+  std::vector<SimMetrics> cur_m(R);
+  // host work per replica may be dealt to worker threads (McPool, host_driver.hpp; option "mc_threads", default 1: at ~0.4 us per
+  // replica the hand-off to spinning workers costs what it saves, measured on the GPU box); replicas own their random streams and state
+  const int T = std::max(1, std::min(e->mc_threads > 0 ? e->mc_threads : 1, (R + 3) / 4));
+  e->mc_threads_used = T;
+  McPool workers(T);
+  std::vector<std::vector<char>> mark(T, std::vector<char>(L));
+  std::atomic<int> fail{DRNA_OK};
+  auto range = [&](int w, int& r0, int& r1) { r0 = (int)((long long)R * w / T); r1 = (int)((long long)R * (w + 1) / T); };
+  auto refresh_pool = [&](int w, int r) {
+    if (targeted) cur_np[r] = targeted_pool(ctx, cur_pq.data() + (size_t)r * L, mark[w].data(), cur_pool.data() + (size_t)r * L);
+  };
+  auto propose_range = [&](int r0, int r1) {
+    for (int r = r0; r < r1; r++) {
+      const int rc = propose_one(ctx, seqs + (size_t)r * L, cur_pool.data() + (size_t)r * L, cur_np[r], p_shelf[r],
+                                 Mt{rng_state + (size_t)r * RNG_WORDS}, prop.data() + (size_t)r * L);
+      if (rc != DRNA_OK) fail.store(rc);
+    }
+  };
+  workers.run([&](int w) {
+    int r0, r1; range(w, r0, r1);
+    for (int r = r0; r < r1; r++) {
+      if (targeted) p_shelf[r] = shelf_probability(ctx, shelf_index[r]);
+      if (!pair_table(mfe_ss + (size_t)r * L, L, cur_pq.data() + (size_t)r * L)) { fail.store(DRNA_ERR_STRUCTURE); continue; }
+      cur_m[r] = sim_metrics(pr, cur_pq.data() + (size_t)r * L, L);
+      refresh_pool(w, r);
+    }
+    if (n_iter > 0 && fail.load() == DRNA_OK) propose_range(r0, r1);
+  });
+  if (fail.load() != DRNA_OK) { e->err = "drna_mc_run: proposal failed (unbalanced structure in the state, or a bad design problem)"; return fail.load(); }
+  static const bool mc_profile = getenv("DRNA_MC_PROFILE") != nullptr;     // diagnostics: where an iteration's host time goes (stderr)
+  double prof[3] = {0, 0, 0};
+  auto now_us = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   for (int it = 0; it < n_iter; it++) {
-    int rc = propose_impl(R, L, target, partner, allowed_mask, n_snakes > 0 ? snake_of : nullptr, snake_off, snake_nodes,
-                          snake_nstates, snake_states, seqs, mfe_ss, shelf_index, n_shelves, tm_max, tm_min, targeted, rng_state,
-                          prop.data());
-    if (rc != DRNA_OK) { e->err = "drna_mc_run: proposal failed"; return rc; }
-    rc = drna_score_batch(e, R, L, prop.data(), flags | DRNA_NEED_PF | DRNA_NEED_MFE | DRNA_NEED_EVAL, pEpf.data(), pEmfe.data(),
-                          pss.data(), pEd.data());
+    const double tp0 = mc_profile ? now_us() : 0.0;
+    int rc = drna_score_batch(e, R, L, prop.data(), flags | DRNA_NEED_PF | DRNA_NEED_MFE | DRNA_NEED_EVAL, pEpf.data(), pEmfe.data(),
+                              pss.data(), pEd.data());
     if (rc != DRNA_OK) return rc;
+    const double tp1 = mc_profile ? now_us() : 0.0;
     if (want_edef) {                        // inside + outside recursion of every proposal (fold_outside.hpp)
       rc = drna_ensemble_defect_batch(e, R, L, prop.data(), pEdef.data(), nullptr);
       if (rc != DRNA_OK) return rc;
     }
-    for (int r = 0; r < R; r++) {
-      // SimScore of the proposal's structure against the target (utils/sim_score.py:62-147)
-      if (!pair_table(pss.data() + (size_t)r * L, L, pq.data())) { e->err = "drna_mc_run: unbalanced MFE structure from the engine"; return DRNA_ERR_STRUCTURE; }
-      long tp = 0, fp = 0, fn = 0, tn = 0;
-      for (int i = 0; i < L; i++) {
-        if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }
-        else if (pr[i] == -1) fp++;
-        else fn++;
-      }
-      double num, den;
-      if (tp == 0 && fp == 0 && fn == 0 && tn != 0) { num = 1; den = 1; }
-      else {
-        num = (double)(tp * tn) - (double)(fp * fn);
-        den = std::sqrt((double)((tp + fp) * (tp + fn) * (tn + fn) * (tn + fp)));
-      }
-      const double mcc = py_round3(num / (den + 0.00001));
-      const double rec = py_round3((double)tp / ((double)(tp + fn) + 0.001));
-      const double pre = py_round3((double)tp / ((double)(tp + fp) + 0.001));
-      const double ed = pEd[(size_t)r * nt] / 100.0;
-      // -sf terms (utils/energy_scores.py:376-398): 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall, 6 Edef
-      double tot = 0.0;
-      for (int k = 0; k < n_terms; k++) {
-        double v;
-        switch (term_id[k]) {
-          case 0: v = ed - pEpf[r]; break;
-          case 1: v = (1 - mcc) * 10; break;
-          case 2: v = (pEpf[r] + 0.3759 * L + 5.7534) / 10; break;
-          case 3: v = ed - pEmfe[r] / 100.0; break;
-          case 4: v = (1 - pre) * 10; break;
-          case 5: v = (1 - rec) * 10; break;
-          case 6: v = pEdef[r]; break;
-          default: e->err = "drna_mc_run: unknown scoring term"; return DRNA_ERR_ARG;
+    const bool more = it + 1 < n_iter;
+    workers.run([&](int w) {
+      int r0, r1; range(w, r0, r1);
+      for (int r = r0; r < r1; r++) {
+        // SimScore of the proposal's structure against the target (utils/sim_score.py:62-147)
+        int* ppq = prop_pq.data() + (size_t)r * L;
+        const bool same_ss = std::memcmp(pss.data() + (size_t)r * L, mfe_ss + (size_t)r * L, (size_t)L) == 0;
+        SimMetrics m = cur_m[r];
+        if (!same_ss) {
+          if (!pair_table(pss.data() + (size_t)r * L, L, ppq)) { fail.store(DRNA_ERR_STRUCTURE); continue; }
+          m = sim_metrics(pr, ppq, L);
         }
-        tot += v * term_w[k];
+        const double ed = pEd[(size_t)r * nt] / 100.0;
+        // -sf terms (utils/energy_scores.py:376-398): 0 Ed-Epf, 1 1-MCC, 2 sln_Epf, 3 Ed-MFE, 4 1-precision, 5 1-recall, 6 Edef
+        double tot = 0.0;
+        for (int k = 0; k < n_terms; k++) {
+          double v = 0.0;
+          switch (term_id[k]) {
+            case 0: v = ed - pEpf[r]; break;
+            case 1: v = (1 - m.mcc) * 10; break;
+            case 2: v = (pEpf[r] + 0.3759 * L + 5.7534) / 10; break;
+            case 3: v = ed - pEmfe[r] / 100.0; break;
+            case 4: v = (1 - m.precision) * 10; break;
+            case 5: v = (1 - m.recall) * 10; break;
+            case 6: v = pEdef[r]; break;
+          }
+          tot += v * term_w[k];
+        }
+        if (nt > 1) {                                           // alternative structures (:98-102)
+          double sum = 0.0;
+          for (int t = 1; t < nt; t++) sum += pEd[(size_t)r * nt + t] / 100.0;
+          tot += sum / (nt - 1) - pEpf[r];
+        }
+        pscore[r] = tot; pmcc[r] = 1 - m.mcc;
+        // Metropolis (utils/replica_exchange_monte_carlo.py:26-57): one draw from the replica's stream, only when the mutant is worse
+        (void)drna_metropolis_batch(1, score + r, pscore.data() + r, temps + r, Lconst, rng_state + (size_t)r * RNG_WORDS, acc.data() + r,
+                                    better.data() + r);
+        if (acc[r]) {
+          std::memcpy(seqs + (size_t)r * L, prop.data() + (size_t)r * L, (size_t)L);
+          if (!same_ss) {
+            std::memcpy(mfe_ss + (size_t)r * L, pss.data() + (size_t)r * L, (size_t)L);
+            std::memcpy(cur_pq.data() + (size_t)r * L, ppq, (size_t)L * sizeof(int));
+            cur_m[r] = m;
+            refresh_pool(w, r);
+          }
+          score[r] = pscore[r]; mcc1[r] = pmcc[r]; Epf[r] = pEpf[r]; Ed[r] = ed;
+        }
       }
-      if (nt > 1) {                                           // alternative structures (:98-102)
-        double sum = 0.0;
-        for (int t = 1; t < nt; t++) sum += pEd[(size_t)r * nt + t] / 100.0;
-        tot += sum / (nt - 1) - pEpf[r];
-      }
-      pscore[r] = tot; pmcc[r] = 1 - mcc;
-    }
-    rc = drna_metropolis_batch(R, score, pscore.data(), temps, Lconst, rng_state, acc.data(), better.data());
-    if (rc != DRNA_OK) return rc;
+      if (more && fail.load() == DRNA_OK) propose_range(r0, r1);          // the next iteration's proposals (same streams, after the Metropolis draw)
+    });
+    if (fail.load() != DRNA_OK) { e->err = "drna_mc_run: unbalanced MFE structure from the engine, or a failed proposal"; return fail.load(); }
+    const double tp2 = mc_profile ? now_us() : 0.0;
+    // counters and the best state, replica by replica in replica order (first strictly better wins)
     for (int r = 0; r < R; r++) {
       if (acc[r]) {
-        std::memcpy(seqs + (size_t)r * L, prop.data() + (size_t)r * L, (size_t)L);
-        std::memcpy(mfe_ss + (size_t)r * L, pss.data() + (size_t)r * L, (size_t)L);
-        score[r] = pscore[r]; mcc1[r] = pmcc[r]; Epf[r] = pEpf[r]; Ed[r] = pEd[(size_t)r * nt] / 100.0;
         counters[0]++;
         if (better[r]) counters[1]++;
         if (mcc1[r] < best[0] || (mcc1[r] == best[0] && score[r] < best[1])) {
@@ -1612,7 +1783,11 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
         }
       } else counters[2]++;
     }
+    if (mc_profile) { prof[0] += tp1 - tp0 - e->timing[3] * 1e3; prof[1] += tp2 - tp1; prof[2] += now_us() - tp2; }
   }
+  if (mc_profile && n_iter > 0)
+    fprintf(stderr, "drna_mc_run: per iteration, host us: score call beyond device time %.1f, per-replica work (%d threads) %.1f, bookkeeping %.1f\n",
+            prof[0] / n_iter, T, prof[1] / n_iter, prof[2] / n_iter);
   return DRNA_OK;
 }
 

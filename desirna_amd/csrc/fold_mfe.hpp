@@ -440,7 +440,7 @@ template <class SM> struct TbShared {
 };
 
 template <class SM, class FMLACC, class QUEUE>
-__device__ inline bool mfe_traceback_q(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
+__device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
                                        const FMLACC FML, const int32_t* __restrict__ EXT, QUEUE Q) {
   const MfeTables& T = *A.T;
   const Plan& P = *A.plan;

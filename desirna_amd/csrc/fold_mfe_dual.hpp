@@ -39,7 +39,7 @@ struct MfeHelperSmem {
 };
 
 template <int NT>
-__device__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
+__device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
   using SM = MfeHelperSmem<NT>;
   constexpr int RS = SM::RS;
   const MfeTables& T = *A.T;

@@ -469,7 +469,7 @@ __device__ __forceinline__ void mfe_e_item_rows(SM& sm, int e, int d, int par, i
 // Uniform bookkeeping comes from LDS tables, not from scalar arithmetic: the scalar unit is shared by
 // the 16 waves and was the bottleneck of earlier versions of this kernel.
 template <int NT, bool DUAL = false>
-__device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT,
+__device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT,
                              int32_t* __restrict__ PL, int32_t* __restrict__ PLX, DualLink lk = DualLink{}) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = MfeFastSmem<NT>::RS;
@@ -850,7 +850,7 @@ __device__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __r
 // one sequence, all pseudoknot rounds: prologue, fill, traceback.  DUAL: the main role of the two-workgroup kernel (lk links
 // it to its helper); every exit publishes DONE so that the helper leaves too
 template <int NT, bool DUAL>
-__device__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
+__device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int r, DualLink lk) {
   if (A.rg.len) A.L = A.rg.len[r];
   const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;      // offset in seqs / ss
   const int n = A.L, ld = A.ld, tid = threadIdx.x;

@@ -308,7 +308,7 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 // KLAG steps after the last of them, so the helper works KROUND diagonals per round (enough items for sixteen waves, one set
 // of barriers) and stays ahead of the main workgroup's need by itself.  Results travel back through DFAR (table 5).
 template <int NT>
-__device__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& EV, PfFastSmem<NT>& sm, int r, int n) {
+__device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& EV, PfFastSmem<NT>& sm, int r, int n) {
   constexpr int NW = NT / WAVE;
   const int ld = A.ld, tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
@@ -376,16 +376,19 @@ __device__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& EV, PfFastSmem<N
 }
 
 template <int NT>
-__device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const EvalArgs& EV) {
+// bx_in / helper_in: the caller's own block -> (sequence slot, role) mapping (fold_fused.hpp); -1 = this kernel's grid (2 bx + role
+// with a helper workgroup per sequence, bx without)
+__device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const EvalArgs& EV, int bx_in = -1, int helper_in = -1) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
   const bool hm = A.helper != 0;                     // a helper workgroup (odd blocks) computes the far multiloop split points
-  const int bx = hm ? blockIdx.x >> 1 : blockIdx.x;
+  const int bx = bx_in >= 0 ? bx_in : hm ? blockIdx.x >> 1 : blockIdx.x;
+  const bool is_helper = hm && (helper_in >= 0 ? helper_in != 0 : (blockIdx.x & 1) != 0);
   const int r = A.rg.idx ? A.rg.idx[bx] : bx;
   if (A.rg.len) A.L = A.rg.len[r];
   const int n = A.L, ld = A.ld;
-  if (hm && (blockIdx.x & 1)) {
+  if (is_helper) {
     if (A.helper == 2) return;                        // fault injection (tests): the helper never shows up, the main workgroup's wait expires
     pf_kfar_helper<NT>(A, EV, sm, r, n);
     return;

@@ -22,7 +22,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 namespace drna_host {
 
@@ -105,41 +109,132 @@ static inline int rnd_choices2(Mt g, double w) {
   return x < c0 ? 0 : 1;                                  // bisect_right(cum_weights, x, 0, 1)
 }
 
-static inline int bracket_family(char ch, bool& open) {
-  static const char OP[] = "([<{ABCDE", CL[] = ")]>}abcde";
-  for (int k = 0; k < 9; k++) {
-    if (ch == OP[k]) { open = true; return k; }
-    if (ch == CL[k]) { open = false; return k; }
+// bracket families of the reference's SimScore (utils/sim_score.py:28-59): code = family << 1 | opening, 0xff = no bracket
+struct BracketLut {
+  unsigned char code[256];
+  BracketLut() {
+    static const char OP[] = "([<{ABCDE", CL[] = ")]>}abcde";
+    for (int k = 0; k < 256; k++) code[k] = 0xff;
+    for (int k = 0; k < 9; k++) { code[(unsigned char)OP[k]] = (unsigned char)(k << 1 | 1); code[(unsigned char)CL[k]] = (unsigned char)(k << 1); }
   }
-  return -1;
-}
+};
+static inline const BracketLut& bracket_lut() { static const BracketLut lut; return lut; }
 
-// partner[i] = j or -1; returns false on unbalanced input
+// partner[i] = j or -1; returns false on unbalanced input.  One stack per bracket family, kept as linked lists through
+// `link` (n ints) so that a call touches O(n) memory whatever the number of families
 static inline bool pair_table(const char* s, int n, int* partner) {
-  int stk[9][2048];
-  int sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (n > 2048) return false;
+  const unsigned char* code = bracket_lut().code;
+  int top[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  int link[2048];
   for (int i = 0; i < n; i++) {
     partner[i] = -1;
-    bool open;
-    const int f = bracket_family(s[i], open);
-    if (f < 0) continue;
-    if (open) stk[f][sp[f]++] = i;
+    const unsigned c = code[(unsigned char)s[i]];
+    if (c == 0xff) continue;
+    const int f = (int)(c >> 1);
+    if (c & 1u) { link[i] = top[f]; top[f] = i; }
     else {
-      if (!sp[f]) return false;
-      const int o = stk[f][--sp[f]];
+      const int o = top[f];
+      if (o < 0) return false;
+      top[f] = link[o];
       partner[o] = i; partner[i] = o;
     }
   }
   for (int f = 0; f < 9; f++)
-    if (sp[f]) return false;
+    if (top[f] >= 0) return false;
   return true;
 }
 
-static inline double py_round3(double x) {   // CPython round(x, 3): correctly rounded decimal, like glibc printf
+// confusion matrix per position of a structure against the reference structure and the three rounded metrics
+// (utils/sim_score.py:62-147): a correct pair counts twice, a base paired to another partner is a false negative
+struct SimMetrics { double mcc, recall, precision; };
+static inline double py_round3_slow(double x) {
   char buf[64];
   snprintf(buf, sizeof buf, "%.3f", x);
   return strtod(buf, nullptr);
+}
+// CPython round(x, 3): the correctly rounded decimal, like glibc printf("%.3f") read back.  Away from a tie the rounded
+// thousandths r are nearbyint(1000 x) and the nearest double to the decimal r / 1000 is the IEEE quotient r / 1000.0 (both
+// operands exact); within 1e-7 of a tie (where the product's own rounding could decide) the decimal conversion decides
+static inline double py_round3(double x) {
+  if (!(std::fabs(x) < 1e5)) return py_round3_slow(x);
+  const double y = x * 1000.0, f = y - std::floor(y);
+  if (std::fabs(f - 0.5) < 1e-7) return py_round3_slow(x);
+  return std::nearbyint(y) / 1000.0;
+}
+
+static inline SimMetrics sim_metrics(const int* pr, const int* pq, int n) {
+  long tp = 0, fp = 0, fn = 0, tn = 0;
+  for (int i = 0; i < n; i++) {
+    if (pr[i] == pq[i]) { if (pr[i] != -1) tp++; else tn++; }
+    else if (pr[i] == -1) fp++;
+    else fn++;
+  }
+  double num, den;
+  if (tp == 0 && fp == 0 && fn == 0 && tn != 0) { num = 1; den = 1; }
+  else {
+    num = (double)(tp * tn) - (double)(fp * fn);
+    den = std::sqrt((double)((tp + fp) * (tp + fn) * (tn + fn) * (tn + fp)));
+  }
+  return SimMetrics{py_round3(num / (den + 0.00001)), py_round3((double)tp / ((double)(tp + fn) + 0.001)),
+                    py_round3((double)tp / ((double)(tp + fp) + 0.001))};
+}
+
+// ---- worker threads of the Monte-Carlo inner loop (drna_mc_run).  The per-replica host work of an iteration (SimScore,
+// Metropolis, state update, next proposal: ~2 us per replica) sits between two kernel launches, i.e. on the critical path of
+// every iteration, and replicas are independent (own random stream, own state), so it is dealt to T threads in contiguous
+// replica ranges.  The workers live for one drna_mc_run call and SPIN between jobs (a futex wake-up costs more than the job);
+// the calling thread is worker 0.
+struct McPool {
+  int T = 1;
+  std::vector<std::thread> th;
+  std::atomic<int> gen{0}, left{0};
+  std::atomic<bool> quit{false};
+  std::function<void(int)> job;                  // job(worker index)
+  explicit McPool(int threads) : T(threads < 1 ? 1 : threads) {
+    for (int w = 1; w < T; w++)
+      th.emplace_back([this, w] {
+        int seen = 0;
+        for (;;) {
+          int spins = 0;
+          while (gen.load(std::memory_order_acquire) == seen) {
+            if (quit.load(std::memory_order_relaxed)) return;
+            if (++spins > 4096) { sched_yield(); spins = 0; } else __builtin_ia32_pause();
+          }
+          seen++;
+          job(w);
+          left.fetch_sub(1, std::memory_order_acq_rel);
+        }
+      });
+  }
+  template <class F> void run(F&& f) {
+    if (T == 1) { f(0); return; }
+    job = std::forward<F>(f);
+    left.store(T - 1, std::memory_order_relaxed);
+    gen.fetch_add(1, std::memory_order_release);
+    job(0);
+    while (left.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+  ~McPool() {
+    quit.store(true);
+    for (auto& t : th) t.join();
+  }
+};
+// CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU lease shows the host's 256 hardware
+// threads and allows a share of them)
+static inline int usable_cpus() {
+  cpu_set_t set;
+  int n = 1;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32]; double per = 0;
+    if (fscanf(f, "%31s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+      const int c = (int)(atof(q) / per + 0.5);
+      if (c >= 1 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n < 1 ? 1 : n;
 }
 
 }  // namespace drna_host

@@ -95,6 +95,47 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert r.returncode == 0 and sorted(x.name for x in tmp_path.iterdir()) == ["rank1.json"]      # one process: this rank only
 
 
+def test_bench_launcher_stops_the_other_ranks_when_one_dies(tmp_path):
+    """A rank that exits non-zero at start-up must not leave the others in the rendezvous: the launcher ends them at once and
+    reports which rank failed (advisor r3: the parent used to block on rank 0's stdout until the backend's own timeout)."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DRNA_BENCH_ECHO_RANK=str(tmp_path), DRNA_BENCH_ECHO_FAIL="1", DRNA_BENCH_ECHO_HANG="0")     # rank 1 dies, rank 0 would sit for 10 minutes
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "ranks failed" in r.stderr and "rank 1 exited with code 3" in r.stderr
+    assert time.time() - t0 < 60
+    # ... and a deadline ends ranks that all hang
+    env.update(DRNA_BENCH_ECHO_FAIL="-", DRNA_BENCH_ECHO_HANG="1", DRNA_BENCH_LAUNCH_TIMEOUT="3")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "deadline reached" in r.stderr and time.time() - t0 < 60
+
+
+def test_bench_strong_scaling_shards(tmp_path):
+    """--scaling strong: --replicas is the TOTAL (the reference's R), replica r on rank r mod N: the shards
+    partition the replicas, their sizes differ by at most one, and every launched rank reports its own share."""
+    import json, os, subprocess, sys
+    import bench
+    from desirna_amd import replica_exchange as rx
+    for R, N in ((64, 1), (64, 2), (64, 4), (64, 8), (10, 4), (7, 8)):
+        shards = [bench.strong_shard(R, k, N) for k in range(N)]
+        assert sorted(x for sh in shards for x in sh) == list(range(R))
+        assert max(len(sh) for sh in shards) - min(len(sh) for sh in shards) <= 1
+        assert shards == [rx.ReplicaShards(R, k, N).local for k in range(N)]        # the design driver's sharding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DRNA_BENCH_ECHO_RANK"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--scaling", "strong", "--replicas", "64"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(3)]
+    assert [g["local_replicas"] for g in got] == [22, 21, 21] and all(g["scaling"] == "strong" for g in got)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["local_replicas"] == 64      # weak: --replicas per GPU
+
+
 def test_tile_product_schedule_never_reads_an_unfinished_operand():
     """fold_pf_strip.hpp deals the chunks of a tile's far range to the 16 steps before the tile is due, from the middle outward
     (tools/pkt_schedule.py restates the plan): every chunk exactly once, and only when both operands are final and visible
