@@ -150,12 +150,14 @@ def roofline_block(dom, dom_ms, L, R, tk, fused=False):
     """The dominant fold kernel against HARDWARE peaks only -- `bound` is the largest of
          hbm : measured HBM bytes per launch (PMC: (2 FETCH_SIZE + WRITE_SIZE) KB) / kernel time / 8 TB/s
          lds : LDS-array busy cycles per CU (SQ_LDS_IDX_ACTIVE / workgroups) / kernel cycles at 2.4 GHz
-         valu: VALU wave-instructions per SIMD (SQ_ACTIVE_INST_VALU / (4 workgroups)) x 2 cycles (SIMD-32 pipe rate,
-               MI355X_MICROARCH.md 'Wave scheduling') / kernel cycles; the 4-cycle figure (what ONE wave alone sustains) is
-               given beside it as frac_wave_issue_4cycle
-    and `own_floor` = time of the same kernel with every sweep phase left out (finalize + barrier only) / kernel time, a
-    property of this implementation, not of the hardware, reported separately.  Counter inputs come from profiles/
-    (rocprofv3 PMC passes and the floor build of the SAME source, tools/gpu_round2.sh); kernel time is measured live here."""
+         valu: VALU wave-instructions per SIMD (SQ_ACTIVE_INST_VALU / (4 workgroups)) x 4 cycles / kernel cycles: MI355X's vector
+               fp64 / int32 rate is 16 lanes per SIMD and clock (78.6 TFLOP/s fp64 over 256 CUs at 2.4 GHz), i.e. 4 cycles per
+               wave64 instruction; only packed or dual-issue fp32 reaches the 2-cycle pipe rate, which is given beside it as
+               frac_pipe_2cycle
+    and `own_floor` = time of the SAME launch configuration built with every sweep phase left out (finalize, hand-shake and
+    barriers only) / kernel time: a property of this implementation, not of the hardware, reported separately.  Counter inputs
+    come from profiles/roofline_inputs.json (rocprofv3 PMC passes and the floor build of the source at the commit named there,
+    tools/gpu_round4.sh); kernel time is measured live here, and a live time more than 5 % away from the profiled run's is flagged."""
     src = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     mfe_b, pf_b = b_alg_bytes(L)
     stream = (pf_b if dom == "pf" else mfe_b) * R
@@ -167,7 +169,8 @@ def roofline_block(dom, dom_ms, L, R, tk, fused=False):
         return out
     try:
         inp = json.load(open(src))
-        k = inp["kernels"]["%s_L%d_R%d" % (dom, L, R)]
+        key = "fused_L%d_R%d" % (L, R) if fused else "%s_L%d_R%d" % (dom, L, R)
+        k = inp["kernels"][key]
     except Exception:
         return out
     t = dom_ms * 1e-3
@@ -188,24 +191,39 @@ def roofline_block(dom, dom_ms, L, R, tk, fused=False):
             # traffic were the main workgroups' (the helpers' is small), their CUs would be this busy
             bounds["lds"]["frac_main_cus_upper"] = a / clk * k["workgroups"] / R
     if k.get("valu_busy_cycles_per_simd"):
-        # the inputs file prices an instruction at 4 cycles (valu_cycles_per_count); the pipe itself takes 2
+        # the inputs file prices an instruction at valu_cycles_per_count (4) cycles
         insts = k["valu_busy_cycles_per_simd"] / inp.get("valu_cycles_per_count", 4.0)
-        a = insts * 2.0 / t
-        bounds["valu"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G VALU pipe cycles/s per SIMD (2 per wave64 instruction)",
-                          "frac": a / clk, "frac_wave_issue_4cycle": insts * 4.0 / t / clk, "wave_instructions_per_simd": insts}
+        a = insts * 4.0 / t
+        bounds["valu"] = {"achieved": a / 1e9, "peak": clk / 1e9, "unit": "G VALU issue cycles/s per SIMD (4 per wave64 fp64 / int32 instruction)",
+                          "frac": a / clk, "frac_pipe_2cycle": insts * 2.0 / t / clk, "wave_instructions_per_simd": insts}
     if bounds:
         name = max(bounds, key=lambda b: bounds[b]["frac"])
         out.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
                     "unit": bounds[name]["unit"], "frac": bounds[name]["frac"], "bounds": bounds,
                     "formulas": {"hbm": "(2*FETCH_SIZE + WRITE_SIZE)*1024 B / kernel_s / 8e12",
                                  "lds": "SQ_LDS_IDX_ACTIVE / workgroups / (kernel_s * 2.4e9)",
-                                 "valu": "SQ_ACTIVE_INST_VALU / (4*workgroups) * 2 / (kernel_s * 2.4e9)"},
+                                 "valu": "SQ_ACTIVE_INST_VALU / (4*workgroups) * 4 / (kernel_s * 2.4e9)"},
                     "inputs": "profiles/roofline_inputs.json (%s)" % inp.get("source", "?")})
     if k.get("floor_ms"):
-        out["own_floor"] = {"floor_ms": k["floor_ms"], "frac": k["floor_ms"] / dom_ms,
-                            "note": "one-workgroup-per-fold build of the same source with every sweep phase left out (finalize + "
-                                    "barrier only): this implementation's dependency chain, not a hardware peak"}
+        out["own_floor"] = {"floor_ms": k["floor_ms"], "frac": k["floor_ms"] / dom_ms, "build": k.get("floor_build"),
+                            "note": "the same launch configuration with every sweep phase left out (finalize, hand-shake and barriers "
+                                    "only): this implementation's dependency chain, not a hardware peak"}
+    if k.get("rocprof_avg_ms"):
+        drift = dom_ms / k["rocprof_avg_ms"] - 1.0
+        out["profiled_kernel_ms"] = k["rocprof_avg_ms"]
+        out["live_vs_profiled"] = drift
+        if abs(drift) > 0.05:
+            out["warning"] = ("live kernel time %.4f ms is %+.1f %% from the profiled run's %.4f ms (%s): counters per launch are "
+                              "from that run" % (dom_ms, 100 * drift, k["rocprof_avg_ms"], inp.get("source", "?")))
+            sys.stderr.write("bench.py: roofline: " + out["warning"] + "\n")
     out["workgroups"] = k.get("workgroups")
+    # both folds of a step: measured HBM bytes of the two launches over the step's device time (BASELINE metric: HBM GB/s vs peak)
+    both = [inp["kernels"].get("%s_L%d_R%d" % (f, L, R), {}).get("hbm_bytes_per_launch") for f in ("mfe", "pf")]
+    if fused:
+        both = [k.get("hbm_bytes_per_launch")]
+    if all(both) and tk.get("total", 0) > 0:
+        out["step_hbm"] = {"bytes_per_step": float(sum(both)), "GB_per_s": sum(both) / (tk["total"] * 1e-3) / 1e9,
+                           "frac_of_peak": sum(both) / (tk["total"] * 1e-3) / 8e12}
     return out
 
 
@@ -491,6 +509,8 @@ def main():
 
     for k in range(args.warmup):
         step(k, False)
+    if multi and args.warmup > 0:
+        step(0, True)                               # one untimed exchange step: the communicator's first collective sets it up
     tk = {"mfe": 0.0, "pf": 0.0, "eval": 0.0, "total": 0.0}
     if multi:
         dist.barrier()
@@ -540,13 +560,15 @@ def main():
             "roofline": roofline_block(dom, tk[dom], L, R, tk, fused),
         }
         rb = out["roofline"]
-        hb = (rb.get("bounds") or {}).get("hbm")
-        out["achieved_hbm_GB_s"] = hb["achieved"] if hb else None          # BASELINE metric: "HBM GB/s vs peak" (8000): both folds of a step
-        out["achieved_hbm_frac_of_peak"] = hb["frac"] if hb else None
+        hb = rb.get("step_hbm")
+        out["achieved_hbm_GB_s"] = hb["GB_per_s"] if hb else None          # BASELINE metric: "HBM GB/s vs peak" (8000): both folds of a step
+        out["achieved_hbm_frac_of_peak"] = hb["frac_of_peak"] if hb else None
         out["sync_fallbacks"] = eng.get_option("sync_fallbacks")          # calls redone with one workgroup per fold (lost partner)
         out["cus_occupied"] = {"workgroups": eng.get_option("last_workgroups"), "compute_units": eng.info()["compute_units"],
-                               "resident_check": ("grid %d <= %d blocks/CU x %d CUs (occupancy query)"
-                                                  % (eng.get_option("last_workgroups"), eng.get_option("fused_blocks_per_cu"), eng.info()["compute_units"])) if fused else None}
+                               # folds by several workgroups: every launch is sized against the occupancy query (engine.hip, pair_blocks_per_cu)
+                               "resident_check": "%d workgroups <= %d blocks/CU x %d CUs (hipOccupancyMaxActiveBlocksPerMultiprocessor)"
+                                                 % (eng.get_option("last_workgroups"), eng.get_option("fused_blocks_per_cu" if fused else "pair_blocks_per_cu"),
+                                                    eng.info()["compute_units"])}
         if per_rank is not None:
             out["ranks"] = {"ms_per_step_min": float(per_rank[:, 0].min()), "ms_per_step_max": float(per_rank[:, 0].max()),
                             "allgather_us_mean": float(per_rank[:, 1].mean()), "allgather_us_max": float(per_rank[:, 1].max()),

@@ -115,8 +115,10 @@ struct drna_engine {
                                   // partition function (fold_pf_lds.hpp, pf_kfar_helper); option "pf_helper"
   int* d_pflags = nullptr;        // its hand-over flags: per sequence two 128-byte lines
   int pflags_cap = 0, pfh_epoch = 0;
-  bool fused = true;              // small batches: both folds in ONE launch of 4 R workgroups (fold_fused.hpp); option "fused", DRNA_FUSED=0
+  bool fused = false;             // small batches: both folds in ONE launch of 4 R workgroups (fold_fused.hpp); option "fused", DRNA_FUSED=1.
+                                  // Off by default: measured 0.5 % slower than the two launches (the host pays the same 14 us either way)
   int fused_blocks_per_cu = -1;   // occupancy query of the fused kernel (-1: not asked yet)
+  int pair_blocks_per_cu = -1;    // ... of the two-workgroup MFE kernel and the partition function with helpers (the smaller of the two answers)
   long long *h_clk = nullptr, *d_clk = nullptr;   // host-mapped: start / end wall clock of every block of the fused launch
   int clk_cap = 0;
   bool last_fused = false;        // the last drna_score_batch_device call went through the fused launch
@@ -399,6 +401,7 @@ extern "C" int drna_get_option(const drna_engine* e, const char* name, int* valu
   if (!strcmp(name, "fused")) { *value = e->fused ? 1 : 0; return DRNA_OK; }
   if (!strcmp(name, "last_fused")) { *value = e->last_fused ? 1 : 0; return DRNA_OK; }
   if (!strcmp(name, "fused_blocks_per_cu")) { *value = e->fused_blocks_per_cu; return DRNA_OK; }
+  if (!strcmp(name, "pair_blocks_per_cu")) { *value = e->pair_blocks_per_cu; return DRNA_OK; }
   if (!strcmp(name, "sync_fallbacks")) { *value = e->sync_fallbacks; return DRNA_OK; }
   if (!strcmp(name, "solo_calls_left")) { *value = e->solo_left; return DRNA_OK; }
   if (!strcmp(name, "last_workgroups")) { *value = e->last_wgs; return DRNA_OK; }
@@ -452,6 +455,21 @@ static void launch_mfe(const MfeArgs& a, int R, hipStream_t s) {
 template <int NT>
 static void launch_pf(const PfArgs& a, int R, hipStream_t s) {
   hipLaunchKernelGGL(pf_kernel<NT>, dim3(R), dim3(NT), 0, s, a);
+}
+
+// Folds by several workgroups that wait for each other (fold_mfe_dual.hpp, pf_kfar_helper) need ALL their workgroups resident at
+// once.  Every such launch is therefore sized against the occupancy query, which is the check hipLaunchCooperativeKernel makes
+// (that call itself costs ~17 us more per launch, MI355X_MICROARCH.md 'coop-launch', and gives the same residency as a plain
+// launch): workgroups of all concurrent launches <= blocks per CU x CUs.  What remains outside the engine's control is another
+// process on the same GPU; the bounded waits and the one-workgroup fallback cover that (ST_SYNC).
+static int pair_blocks_per_cu(drna_engine* e) {
+  if (e->pair_blocks_per_cu < 0) {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mfe_dual_kernel<1024>, 1024, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pf_lds_kernel<1024>, 1024, 0) != hipSuccess) b = 0;
+    e->pair_blocks_per_cu = std::min(a, b);
+  }
+  return e->pair_blocks_per_cu;
 }
 
 // The fused launch's workgroups wait for each other, so the whole grid must be resident at once: the grid is checked against
@@ -510,7 +528,8 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // (R = 64 x L = 200: the MFE fold takes 0.50 instead of 0.59 ms, 1.65 instead of 1.81 ms with the pseudoknot re-folds; the
   // partition function running beside it loses 1 % to the busier chip's lower clock)
   // Shorter sequences do not repay the hand-shake (measured break-even at n = 160: tools/dual_lengths.py).
-  const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4 * R <= e->cus &&
+  const long long resident = (long long)e->cus * ((e->dual || e->pf_helper) && e->nt == 1024 ? pair_blocks_per_cu(e) : 1);   // workgroups the chip holds at once
+  const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4ll * R <= resident &&
                         (L >= 170 || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
@@ -545,7 +564,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // points (the main workgroup's vector-memory path is what they saturate); needs room for 2 R workgroups beside the MFE fold's
   const int mfe_wgs = want_mfe ? (use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R) : 0;
   const bool pf_help = want_pf && e->pf_helper && !pf_strips && e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX && L >= PF_HELPER_NMIN &&
-                       2 * R + mfe_wgs <= e->cus;
+                       2ll * R + mfe_wgs <= resident;
   if (pf_help) {
     if (e->pflags_cap < R) {
       if (e->d_pflags) (void)hipFree(e->d_pflags);
@@ -630,10 +649,6 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->last_wgs += use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R;
     if (use_dual) {
       DualLink lk = make_dual_link();
-#ifdef DRNA_DUALDBG
-      lk.dbg = reinterpret_cast<long long*>(e->d_ws_mfe + 2 * (size_t)ld * ld + 8192);  // table 2 of sequence 0's workspace is unused by the LDS kernels
-      (void)hipMemsetAsync(lk.dbg, 0, 64 * 64 * sizeof(long long), e->s_mfe);
-#endif
       hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_mfe, a, lk);
     } else if (mfe_strips && a.pk_rounds > 0 && R >= 16 * e->mfe_split && e->mfe_split > 1) {
       // every round is a fill launch and a traceback launch (one wave per sequence, ~0.2 ms with the chip idle): the batch goes
@@ -721,15 +736,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   if (want_ev && s_ev == e->s_eval) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
   // join on the host: the streams are drained one after the other (a device-side join -- stream-wait-event packets
   // plus an end marker -- costs ~15 us after the last kernel); "total" = first start event to the latest end event
-#ifdef DRNA_SPINWAIT
-  auto drain = [&](hipStream_t st) -> hipError_t {       // poll instead of the runtime's blocking wait
-    hipError_t q;
-    while ((q = hipStreamQuery(st)) == hipErrorNotReady) { }
-    return q;
-  };
-#else
   auto drain = [&](hipStream_t st) -> hipError_t { return hipStreamSynchronize(st); };
-#endif
   if (want_ev && !ev_in_pf && s_ev == e->s_eval) HIP_TRY(drain(e->s_eval));
   if (mfe_first && want_pf) HIP_TRY(drain(e->s_pf));
   if (want_mfe) HIP_TRY(drain(e->s_mfe));
@@ -1791,7 +1798,7 @@ extern "C" int drna_mc_run(drna_engine* e, int R, int L, int n_iter, const char*
   return DRNA_OK;
 }
 
-#if defined(DRNA_STAMPS) || defined(DRNA_STAMPS_API) || defined(DRNA_TL)
+#if defined(DRNA_STAMPS) || defined(MSTRIP_STAMPS) || defined(DRNA_TL)
 // diagnostic build only: copy `count` int32 of the MFE workspace starting at int32 offset `off`
 extern "C" int drna_debug_read_mfe_ws(drna_engine* e, long long off, int count, int32_t* out) {
   if (!e || !out) return DRNA_ERR_ARG;

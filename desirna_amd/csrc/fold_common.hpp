@@ -3,6 +3,13 @@
 #include <stdint.h>
 
 #include "tables.hpp"
+// the hardware primitives (agent-scope loads / stores, counted waits, the spin clock, ds_bpermute, the fp64 matrix instruction):
+// gfx950_prims.hpp -- or the CPU stand-ins the kernels' test emulation supplies (tests/emu; the ONLY place the product knows of it)
+#ifdef DRNA_PRIMS_HEADER
+#include DRNA_PRIMS_HEADER
+#else
+#include "gfx950_prims.hpp"
+#endif
 
 namespace drna {
 
@@ -44,7 +51,6 @@ struct DualLink {
   int32_t* xs = nullptr;          // main -> helper: pairing codes Sp[0 .. n+1] of the round (4 = masked)
   void* xa = nullptr;             // main -> helper rows (ring word, fML)
   void* xb = nullptr;             // helper -> main rows (split minima, far-shape minima)
-  long long* dbg = nullptr;       // diagnostic builds (-DDRNA_DUALDBG): cycle counters, 64 words per sequence
   int base = 0;                   // ((epoch * 8 + round) << 10)
   int epoch = 0;
 };
@@ -52,54 +58,6 @@ __device__ __forceinline__ int dual_base(int epoch, int round) { return (int)(((
 __device__ __forceinline__ int dual_done(int epoch) { return (int)((((unsigned)epoch * 8u + 7u) << 10) + 1023u); }
 __device__ __forceinline__ bool flag_ge(int v, int target) { return (int)((unsigned)v - (unsigned)target) >= 0; }
 
-#ifdef DRNA_EMU
-template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { T v; __atomic_load(p, &v, __ATOMIC_ACQUIRE); return v; }
-template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
-__device__ __forceinline__ void drain_vmem() {}
-__device__ __forceinline__ void spin_pause() { sched_yield(); }
-#else
-template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
-#endif
-// wait until at most N of the wave's vector-memory operations are outstanding (they retire in issue order)
-template <int N>
-__device__ __forceinline__ void stores_in_flight() {
-#ifndef DRNA_EMU
-  if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-// A wait for another workgroup is bounded by TIME (round 3; it was 2^22 polls, about 4 s): HIP promises no dispatch order, so a
-// partner may never have been scheduled, and the engine then redoes the call with one workgroup per fold -- which must not cost
-// seconds.  10 ms of the 100 MHz wall clock is far beyond any legitimate wait (a whole 2046-nt fold by strips takes 35 ms and its
-// strips wait for each other one diagonal at a time) and keeps a lost call in the tens of milliseconds.  The CPU emulation of the
-// kernels (tests/emu) counts polls instead.
-constexpr int SPIN_LIMIT = 1 << 22;
-constexpr long long SPIN_BUDGET_TICKS = 1000000;          // 10 ms at 100 MHz
-struct SpinClock {
-#ifdef DRNA_EMU
-  int n = 0;
-  __device__ __forceinline__ bool expired() { return ++n > SPIN_LIMIT; }
-#else
-  long long t0 = (long long)wall_clock64();
-  int n = 0;
-  __device__ __forceinline__ bool expired() { return (++n & 15) == 0 && (long long)wall_clock64() - t0 > SPIN_BUDGET_TICKS; }
-#endif
-};
-#ifdef DRNA_DUALDBG
-#define DDBG(stmt) do { stmt; } while (0)
-#else
-#define DDBG(stmt) do { } while (0)
-#endif
 // all lanes of the calling wave poll the same word (one request); returns false when the wait expired
 __device__ __forceinline__ bool wait_flag_wave(const int* flag, int target) {
   SpinClock clk;
@@ -110,16 +68,6 @@ __device__ __forceinline__ bool wait_flag_wave(const int* flag, int target) {
   }
 }
 
-// all lanes of the wave have executed their LDS operations up to here (wave-private staging through LDS)
-__device__ __forceinline__ void wave_lds_sync() {
-#ifdef DRNA_EMU
-  pthread_barrier_wait(&emu_g->waves[threadIdx.x >> 6].bar);
-#else
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-#endif
-}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -277,27 +225,18 @@ __device__ __forceinline__ int rtype_of(int t) {
 
 // ---- strip kernels (fold_pf_strip.hpp, fold_mfe_strip.hpp): one sequence folded by several workgroups, each owning a strip
 // of columns i; dependencies between strips run one way (towards smaller i), see fold_pf_strip.hpp
-#ifndef STRIP_DIAG
-#define STRIP_DIAG 0     // diagnostic builds only (timing; results wrong): 1 plain table stores, 2 plain multiloop loads, 4 no waits / records in,
-#endif                   // 8 barrier without store drain, 16 no record exports
-#ifndef DRNA_STRIP_PAD
-#define DRNA_STRIP_PAD 1
-#endif
 // Empty blocks per sequence behind its strips.  Workgroups of an XCD are dealt to its shader engines in turn and start in order:
 // with four strips per sequence and no padding, strip s of EVERY sequence lands on engine s, the long-lived last strips queue
 // behind each other on a quarter of the CUs and the rest idles (measured: tools/strip_clocks.py).  One empty block per
 // sequence rotates the assignment.
-constexpr int STRIP_PAD = DRNA_STRIP_PAD;
+constexpr int STRIP_PAD = 1;
 // ... so that S + pad is ODD: with an even number of blocks per sequence the strips still fall on the same engines in turn
 // (three strips + one empty block: strip s of every sequence on engine s again, n = 300 at R = 128: PF 2.58 vs 2.07 ms)
 __host__ __device__ inline int strip_pad(int S) { return STRIP_PAD ? ((S & 1) ? 0 : 1) : 0; }
 constexpr int STRIP_DONE = 4095, STRIP_FAIL = 4094;   // flag values above every diagonal
 constexpr int STRIP_REC = 88;                         // doubles per exchange record
 constexpr int STRIP_MAXS = 18;                         // strips per sequence at most
-#ifndef DRNA_STRIP_WMAX
-#define DRNA_STRIP_WMAX 120
-#endif
-constexpr int STRIP_WMAX = DRNA_STRIP_WMAX;                       // widest strip of the production kernel (1024 threads)
+constexpr int STRIP_WMAX = 120;                       // widest strip of the production kernel (1024 threads)
 constexpr int STRIP_NMAX = STRIP_MAXS * STRIP_WMAX;   // longest sequence
 
 struct StripLink {
@@ -314,13 +253,11 @@ struct StripLink {
   long long* clk = nullptr;  // diagnostics: start / end wall clock (100 MHz) of every strip workgroup, [slot][STRIP_MAXS][2]
 };
 // Layout of the strips of an n-nt sequence.  The LAST strip (columns from 1: it lives through all n diagonals, and its
-// multiloop sums are the longest) is narrower than the others: DRNA_STRIP_SKEW percent of the mean width, at least 32 columns
-// (a halo reaches 31); the strips above it share the rest evenly, at most `wmax` columns each.
-#ifndef DRNA_STRIP_SKEW
-#define DRNA_STRIP_SKEW 100
-#endif
+// multiloop sums are the longest) gets the mean width, at least 32 columns (a halo reaches 31); the strips above it share the
+// rest evenly, at most `wmax` columns each.  (Narrowing the last strip to 75 / 55 / 40 % of the mean: 5.07 / 5.13 / 5.30 vs 4.81 ms
+// at 400 nt x 256 -- the strips are bound by the latency of a step, not by the last strip's share.)
 __host__ __device__ inline int strip_last_width(int n, int S) {
-  int w = (n * DRNA_STRIP_SKEW + 50 * S) / (100 * S);
+  int w = (n + S / 2) / S;
   return w < 32 ? 32 : w;
 }
 __host__ __device__ inline int strip_upper_width(int n, int S) { return S > 1 ? (n - strip_last_width(n, S) + S - 2) / (S - 1) : 0; }
@@ -354,27 +291,17 @@ __device__ __forceinline__ bool strip_wait(const int* flag, int base, int d, int
   }
 }
 
-#if STRIP_DIAG & 8
-#define STRIP_BARRIER() lds_barrier()
-#else
-#define STRIP_BARRIER() __syncthreads()
-#endif
-template <typename T> __device__ __forceinline__ void strip_store(T* p, T v) {
-#if STRIP_DIAG & 1
-  *p = v;
-#else
-  st_agent(p, v);
-#endif
-}
+#define STRIP_BARRIER() __syncthreads()      // (drains the wave's stores too: the hand-over relies on it)
+template <typename T> __device__ __forceinline__ void strip_store(T* p, T v) { st_agent(p, v); }
 // 8-byte buffer load that bypasses this CU's L1 (sc1): for cells another workgroup stored
 template <typename RS>
 __device__ __forceinline__ double buf_load_f64_aux(RS rsrc, int voff, int soff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 16);
   return __hiloint2double((int)v[1], (int)v[0]);
 }
 template <typename RS>
 __device__ __forceinline__ f64x2 buf_load_f64x2_sc1(RS rsrc, int voff, int soff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);     // aux 16 = sc1: bypasses this CU's L1
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16);     // aux 16 = sc1: bypasses this CU's L1
   return f64x2{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
 }
 

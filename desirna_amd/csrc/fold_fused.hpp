@@ -40,7 +40,7 @@ __global__ __launch_bounds__(NT) void score_fused_kernel(MfeArgs MA, DualLink lk
   int r, role;
   fused_block_role(blockIdx.x, r, role);
   if (r >= R) return;
-  if (clk && threadIdx.x == 0) clk[2 * blockIdx.x] = (long long)wall_clock64();
+  if (clk && threadIdx.x == 0) clk[2 * blockIdx.x] = wall_clock_100mhz();
   if (role == ROLE_MFE_MAIN || role == ROLE_MFE_HELPER) {
     lk.flagA += r * 64; lk.flagB += r * 64 + 32;
     lk.xs += (long long)r * 256;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NT) void score_fused_kernel(MfeArgs MA, DualLink lk
   } else {
     pf_lds_body<NT>(*reinterpret_cast<PfFastSmem<NT>*>(raw), PA, EV, r, role == ROLE_PF_HELPER ? 1 : 0);
   }
-  if (clk && threadIdx.x == 0) clk[2 * blockIdx.x + 1] = (long long)wall_clock64();
+  if (clk && threadIdx.x == 0) clk[2 * blockIdx.x + 1] = wall_clock_100mhz();
 }
 
 }  // namespace drna

@@ -417,7 +417,11 @@ template <class SM> struct TbShared {
     if (c > (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])) - 1) return false;
     for (;;) {
       const int m = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned char*>(&sm.sec_ml[c]));
-      if (m) { i = sm.sec_i[c]; j = sm.sec_j[c]; ml = m - 1; return true; }
+      if (m) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // pairs with push()'s release: the payload loads stay behind the flag read
+        i = sm.sec_i[c]; j = sm.sec_j[c]; ml = m - 1;
+        return true;
+      }
       if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&sm.tbq[3]))) return false;
       spin_pause();
     }
@@ -426,7 +430,10 @@ template <class SM> struct TbShared {
     if (lane_id() == 0) {
       atomicAdd(&sm.tbq[2], 1);
       const int c = atomicAdd(&sm.tbq[1], 1);
-      if (c > (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])) - 1) { *reinterpret_cast<volatile int*>(&sm.tbq[3]) = 2; return; }   // (cannot happen for n <= NLEN)
+      // The queue is append-only, so it must hold every sector of a structure at once: each push is a distinct interval that
+      // holds a pair of its own (an exterior stem or a multiloop branch), hence at most n / 2 + 1 <= NLEN + 2 entries.  The guard
+      // is for a corrupted table only; it ends the traceback as a failure (ST_TRACEBACK), like every table value it cannot reproduce.
+      if (c > (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])) - 1) { *reinterpret_cast<volatile int*>(&sm.tbq[3]) = 2; return; }
       sm.sec_i[c] = (short)i; sm.sec_j[c] = (short)j;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       *reinterpret_cast<volatile unsigned char*>(&sm.sec_ml[c]) = (unsigned char)(ml + 1);

@@ -101,7 +101,6 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     if (lane == 0) { sm.pcnt[par] = cnt; sm.qhead[par] = 0; }
   };
 
-  DDBG(if (tid == 0) lk.dbg[15] -= clock64());
   bool failed = false;
   for (int round = 0; round <= A.pk_rounds; round++) {
     const int base = dual_base(lk.epoch, round);
@@ -127,9 +126,7 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
         if (D + 1 < n) {
           const int dr = D + 1 - DLAG;
           if (dr > TURN) {
-            DDBG(if (lane == 0) lk.dbg[8] -= clock64());
             if (!flag_ge(__builtin_amdgcn_readfirstlane(fa), base + dr) && !wait_flag_wave(lk.flagA, base + dr)) sm.failr[D & 1] = 1;
-            DDBG(if (lane == 0) { const long long t = clock64(); lk.dbg[8] += t; lk.dbg[9] -= t; });
             const int ro = fml_off(dr, n);
             int vw[4], vf[4];                                    // all eight loads in flight, then the LDS stores
 #pragma unroll
@@ -144,14 +141,11 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
               const int i = c * WAVE + lane + 1;
               if (i <= n - dr) { sm.wring[(dr & 31) * RS + i] = vw[c]; sm.fml[ro + i - 1] = vf[c]; }
             }
-            DDBG(if (lane == 0) lk.dbg[9] += clock64());
           }
         }
         fa = ld_agent(lk.flagA);                       // for the next step (left in flight across the barrier)
       } else if (wave == 2) {
-        DDBG(if (lane == 0) lk.dbg[10] -= clock64());
         if (D + 1 < n) prepare(D + 1);               // tables of the next diagonal (sequence only: no wait)
-        DDBG(if (lane == 0) lk.dbg[10] += clock64());
       } else if (wave == 1) {
         // ---- outbound: the flag of diagonal D-2 (its minima were stored during the previous step: they have landed by
         // now, so the wait is short), then the minima of diagonal D-1 (reset for diagonal D+1)
@@ -159,36 +153,28 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
         if (lane == 0 && D - 2 > TURN) st_agent(lk.flagB, base + D - 2);
         const int ds = D - 1;
         if (ds > TURN && ds < n) {
-          DDBG(if (lane == 0) lk.dbg[11] -= clock64());
           const int ps = ds & 1;
           for (int i = lane + 1; i <= n - ds; i += WAVE) {
             st_agent(xk + ds * XP + i, (int32_t)sm.accK[ps][i]);
             st_agent(xi + ds * XP + i, (int32_t)sm.accI[ps][i]);
             sm.accK[ps][i] = INF; sm.accI[ps][i] = INF;
           }
-          DDBG(if (lane == 0) lk.dbg[11] += clock64());
         }
       } else if (D < n) {
         // ---- workers: K items (32-cell blocks of split sweeps), then the far-shape items of the pairable cells
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
-        const int nK = (ncell + 31) >> 5, nE = e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);
+        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);      // (DRNA_SKIP: timing builds)
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
-        DDBG(if (lane == 0 && wave == 3) lk.dbg[12] -= clock64());
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
-          DDBG(if (lane == 0 && wave == 3) lk.dbg[14]++);
           if (it < nK) mfe_k_item(sm, it, D, n, ncell, par, 0, lane, TURN + 1 + KEDGE, D - TURN - 2 - KEDGE);
           else mfe_e_item<E_FAR>(sm, it - nK, D, par, pcnt, 0, lane, TermAU, e_bulge1, e_int23);
         }
-        DDBG(if (lane == 0 && wave == 3) lk.dbg[12] += clock64());
       }
-      DDBG(if (tid == 0) lk.dbg[13] -= clock64());
       __syncthreads();
-      DDBG(if (tid == 0) lk.dbg[13] += clock64());
       if (sm.failr[D & 1]) { failed = true; break; }         // (the other parity's word is the one step D+1 may write)
     }
     if (failed) break;
   }
-  DDBG(if (tid == 0) lk.dbg[15] += clock64());
 }
 
 // grid = 2 R workgroups: 2r = main, 2r+1 = helper of sequence r.  LDS is one buffer used as either role's struct.
@@ -202,7 +188,6 @@ __global__ __launch_bounds__(NT) void mfe_dual_kernel(MfeArgs A, DualLink lk) {
   lk.xs += (long long)r * 256;
   lk.xa = reinterpret_cast<int32_t*>(lk.xa) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
   lk.xb = reinterpret_cast<int32_t*>(lk.xb) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
-  DDBG(lk.dbg += r * 64);
   if (blockIdx.x & 1) mfe_helper<NT>(*reinterpret_cast<MfeHelperSmem<NT>*>(raw), A, r, lk);
   else mfe_lds_body<NT, true>(*reinterpret_cast<MfeFastSmem<NT>*>(raw), A, r, lk);
 }

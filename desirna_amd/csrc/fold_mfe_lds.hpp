@@ -76,20 +76,12 @@ struct FmlLds {
 #ifndef DRNA_SKIP
 #define DRNA_SKIP 0          // diagnostic builds only: see fold_pf_lds.hpp
 #endif
-#ifdef DRNA_PROCLK
-#define PCLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long*>(A.ws + 2ll * A.ld * A.ld)[512 + (k)] = clock64(); } while (0)
-#else
-#define PCLK(k) do { } while (0)
-#endif
-#ifndef DRNA_FSKIP
-#define DRNA_FSKIP 0         // diagnostic builds only: parts of the cell finalize left out (1 stores, 2 hairpin, 4 fML, 8 side jobs, 16 all of it, 32 exterior stem)
-#endif
 #ifdef DRNA_STAMPS
 #define STAMP(k) do { long long _n = clock64(); st_acc[k] += _n - st_last; st_last = _n; } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
-// -DDRNA_TL -DDRNA_FIN_SYNC (tools/timeline.py mfe): raw 100 MHz clocks per wave and step of sequence 0's main workgroup, into
+// -DDRNA_TL (tools/timeline.py mfe): raw 100 MHz clocks per wave and step of sequence 0's main workgroup, into
 // the unused table 2 of its workspace: 0 after the barrier, 1 after the finalize / tower step, 2 after the last item
 #ifdef DRNA_TL
 #define MTLMARK(ev, k) do { if (mtl_on && lane == 0) mtl[((wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
@@ -249,10 +241,7 @@ __device__ __forceinline__ void mfe_k_edge_item(SM& sm, int it, int d, int n, in
 // of a per-lane shape decode.  MODE: E_ALL = every shape (one-workgroup kernel); E_NEAR / E_FAR = the split of the
 // two-workgroup kernel: NEAR are the shapes whose inner pair sits at most four diagonals back ((0,0) (0,1) (1,0) (1,1)
 // (0,2) (2,0): one item per block), FAR everything else (its etab marks the two near bulges as padding).
-#ifndef DRNA_ECOARSE
-#define DRNA_ECOARSE 32
-#endif
-constexpr int ECOARSE = DRNA_ECOARSE;   // at most this many pairable cells on the diagonal: coarse E items
+constexpr int ECOARSE = 32;   // at most this many pairable cells on the diagonal: coarse E items
 constexpr int ESH = 10, EPB = 13;   // one-workgroup kernel: shapes per E item; E items per block of 64 pairable cells (4 classes x 3 parts + small shapes)
 constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge class (u = 2 .. DLAG-3) and per 1xn class (u = 3 .. DLAG-4)
 template <int MODE>
@@ -569,7 +558,6 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     if (lane == 0) PL[d * ld + ld - 1] = base;     // count kept in the last word of the row
   }
   __syncthreads();
-  PCLK(2);
   if (DUAL) {
     // round prologue for the helper workgroup: the pairing codes of this round (masked positions = 4), then the flag
     int32_t* xs = lk.xs;
@@ -598,7 +586,6 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   long long* mtl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
   const bool mtl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0;
 #endif
-  PCLK(3);
   if (aw < 0) {
     // ================= finalize waves
     // two-workgroup kernel: the helper's results for diagonal d (split minima, far-shape minima) are fetched one step AHEAD
@@ -611,7 +598,6 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     int pfK = INF, pfI = INF, fb_s = 0;
     bool have = false;
     if (DUAL) fb_s = __builtin_amdgcn_readfirstlane(ld_agent(lk.flagB));
-    DDBG(if (tid == 0) lk.dbg[2] -= clock64());
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       MTLMARK(0, k);
@@ -626,10 +612,8 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
         rq_have = d + 1 < n && flag_ge(fb_s, lk.base + d + 1);
         rq_on = rq_have && i2 >= 1 && i2 <= n - d - 1;
-#ifndef DRNA_DBG_NOPF
         rqK = ld_agent(rq_on ? xk + (d + 1) * XP + i2 : lk.flagB);
         rqI = ld_agent(rq_on ? xi + (d + 1) * XP + i2 : lk.flagB);
-#endif
         rqF = ld_agent(lk.flagB);
       }
       // ---- top of the step: requests of the pipelined side jobs
@@ -662,15 +646,13 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         int bK = pfK, bI = pfI;
         if (DUAL) {
           if (!have) {                                           // not fetched ahead: wait for the helper here
-            DDBG(if (tid == 0) { lk.dbg[0]++; lk.dbg[1] -= clock64(); });
             if (!sm.sync_fail && !wait_flag_wave(lk.flagB, lk.base + d)) sm.sync_fail = 1;
-            DDBG(if (tid == 0) lk.dbg[1] += clock64());
             const bool on = i >= 1 && i <= ncell;
             bK = on ? ld_agent(xk + d * XP + i) : INF;
             bI = on ? ld_agent(xi + d * XP + i) : INF;
           }
         }
-        if (!(DRNA_FSKIP & 16) && i >= 1 && i <= ncell) {
+        if (i >= 1 && i <= ncell) {
           const int aG = sm.accG[par][tid];
           const int aI = DUAL ? min(sm.accI[par][tid], bI) : sm.accI[par][tid];
           const int aK = DUAL ? min(sm.accK[par][tid], bK) : sm.accK[par][tid];
@@ -681,7 +663,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           int c = INF, info = 0, cb = INF;
           if (t) {
             const int ij = t * 16 + sm.S[i + 1] * 4 + sm.S[j - 1];
-            c = (DRNA_FSKIP & 2) ? 100 : mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
+            c = mfe_hairpin_e(sm, T, sm.hpl[dm1v], i, j, t);
             c = min(c, aI);
             c = min(c, aG + sm.mmI[ij]);
             const int dml = sm.dml[((d - 2) & 3) * RS + i + 1];
@@ -693,12 +675,12 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           }
           sm.wring[(d & 31) * RS + i] = cb * 256 + info;
           sm.ciring[(d & 31) * RS + i] = c < INF ? c + sm.mmI[info] : INF;
-          if (!(DRNA_FSKIP & 1)) {
+          {
             Wc[d * ld + i] = c * 256 + info;
-            EXT[j * ld + i] = c < INF ? c + tau + ((DRNA_FSKIP & 32) ? 0 : mfe_extstem(sm, t, i, j, n)) : INF;
+            EXT[j * ld + i] = c < INF ? c + tau + mfe_extstem(sm, t, i, j, n) : INF;
           }
           int f = INF;
-          if (!(DRNA_FSKIP & 4) && d - 1 > TURN) {
+          if (d - 1 > TURN) {
             const int ro1 = sm.rowoff[dm1v];
             const int fa = sm.fml[ro1 + i], fb = sm.fml[ro1 + i - 1];
             if (fa < HALF) f = fa + MLbase;
@@ -710,17 +692,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           const int fv = min(f, dec);
           sm.fml[sm.rowoff[dv] + i - 1] = fv;
           if (DUAL) {                                            // the helper's copies of the ring word and of fML
-#ifndef DRNA_DBG_NOST
             st_agent(xw + d * XP + i, cb * 256 + info);
             st_agent(xf + d * XP + i, fv);
-#endif
           }
         }
       }
       // side jobs of the step, one finalize wave each (when there are that many): tower table and pairable list of
       // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
       // <= k-4, were stored in step <= k-3 and had landed by the end of step k-2)
-      if (!(DRNA_FSKIP & 8) && k + 1 < n) {
+      if (k + 1 < n) {
         if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio, DUAL ? E_NEAR : E_ALL);
         if (wave == w_pl) {
           const int dn = k + 1;
@@ -746,14 +726,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       }
       STAMP(4);
       MTLMARK(1, k); MTLMARK(2, k);
-      DDBG(if (tid == 0) lk.dbg[3] -= clock64());
       // every global load of the step has been consumed; what is still in flight are this step's stores (c, exterior term,
       // and the two published words of the two-workgroup kernel): the wait lets exactly those stay in flight across the
       // barrier, so the stores of the PREVIOUS step have landed -- which is what their readers rely on (exterior column
       // three steps later, flagA two steps later) -- and no store latency sits in the step
-#ifdef DRNA_FIN_SYNC
-      __syncthreads();
-#else
       bool stored = false;
       if (d > TURN) { const int i_ = tid + 1 - (d >> 1) - off0; stored = __ballot(i_ >= 1 && i_ <= n - d) != 0ull; }
       if (DUAL && d > TURN) {
@@ -764,10 +740,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       // the requests above are older than the stores, so once they are in, everything of the previous steps has landed; this
       // step's own stores (2, or 4 in the two-workgroup kernel) stay in flight across the barrier
       if (stored) stores_in_flight<DUAL ? 4 : 2>(); else stores_in_flight<0>();
-      DDBG(if (tid == 0) { const long long t = clock64(); lk.dbg[3] += t; lk.dbg[4] -= t; });
       lds_barrier();                       // one barrier per diagonal
-#endif
-      DDBG(if (tid == 0) lk.dbg[4] += clock64());
       STAMP(3);
     }
   } else {
@@ -839,7 +812,6 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
   }
 #endif
-  PCLK(4);
   // the remaining exterior columns (every store has landed: the loop ended with a draining barrier)
   if (wave == 0) {
     for (int j = max(TURN + 2, n - 2); j <= n; j++) mfe_f5_column<NT>(sm, EXT, ld, j, lane);
@@ -861,7 +833,6 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
   int32_t* EXT = base + 4 * tab;
   int32_t* PL = base + 3 * tab;      // compacted pairable-cell lists, one row per diagonal
   int32_t* PLX = base + 1 * tab;     // their staged (1,2) / (2,1) loop energies
-  PCLK(0);
 
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
   for (int k = tid; k < 128; k += NT) {
@@ -895,16 +866,8 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
   int status = ST_OK;
   for (int round = 0; round <= A.pk_rounds; round++) {
     for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
-#ifdef DRNA_PHASECLK
-    const long long pc0 = wall_clock64();
-#endif
     lk.base = dual_base(lk.epoch, round);
-    PCLK(1);
     mfe_fill_lds<NT, DUAL>(sm, A, Wc, EXT, PL, PLX, lk);           // ends with a barrier
-    PCLK(5);
-#ifdef DRNA_PHASECLK
-    const long long pc1 = wall_clock64();
-#endif
     if (DUAL && sm.sync_fail) { status = ST_SYNC; break; }
     // traceback by TB_WAVES waves working from one queue of sectors in LDS (TbShared): entry 0 = the whole exterior interval
     constexpr int TB_WAVES = NT / WAVE < 8 ? NT / WAVE : 8;
@@ -917,16 +880,11 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
     __syncthreads();
     if (!(DRNA_SKIP & 256) && wave_id() < TB_WAVES) (void)mfe_traceback_q(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT, TbShared<MfeFastSmem<NT>>{sm});
     __syncthreads();
-#ifdef DRNA_PHASECLK
-    if (blockIdx.x == 0 && tid == 0)
-      printf("mfe_lds_kernel: fill %lld traceback %lld (100 MHz ticks)\n", pc1 - pc0, wall_clock64() - pc1);
-#endif
     if (tid == 0) {
       if (round == 0) A.Emfe[r] = sm.f5[n];
       sm.flag = (!(DRNA_SKIP & 256) && sm.tbq[3] == 2) ? 1 : 0;
     }
     __syncthreads();
-    PCLK(6);
     if (sm.flag) { status = ST_TRACEBACK; break; }
     const char op = round == 0 ? '(' : round == 1 ? '[' : round == 2 ? '<' : '{';
     const char cl = round == 0 ? ')' : round == 1 ? ']' : round == 2 ? '>' : '}';
@@ -947,10 +905,8 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
     if (!more) break;
   }
   if (DUAL && tid == 0) st_agent(lk.flagA, dual_done(lk.epoch));
-  DDBG(if (tid == 0) lk.dbg[2] += clock64());
   for (int k = tid; k < n; k += NT) A.ss[so + k] = sm.sspk[k];
   if (tid == 0) A.status[r] = status;
-  PCLK(7);
 }
 
 template <int NT>

@@ -23,16 +23,11 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #else
 #define MST(k) do { } while (0)
 #endif
-#ifndef MSTRIP_LEAD
-#define MSTRIP_LEAD 0
-#endif
 #ifndef MSTRIP_SKIP
 #define MSTRIP_SKIP 0     // diagnostic builds only (results wrong): 1 no multiloop items, 2 no shape items, 4 no tower step, 8 no cell finalize, 128 split items without their second operand's loads, 256 those loads plain
 #endif
 
-#ifndef MSTRIP_KU
-#define MSTRIP_KU 8       // split points per lane and round trip in the big batches (2 x 16-byte loads each)
-#endif
+constexpr int MSTRIP_KU = 8;       // split points per lane and round trip in the big batches (2 x 16-byte loads each)
 // ---- blocked multiloop splits (StripLink::fark, chosen per launch by the engine: long folds).  With m = i + tt + 2 the split
 // minimum of cell (i, j) is min_m fML(i, m-1) + fML(m, j), m = i + TURN + 2 .. j - TURN - 1: a (min,+) matrix product.  Same
 // geometry and schedule as the blocked sums of the partition function (fold_pf_strip.hpp, which has the derivation): tiles of
@@ -51,26 +46,14 @@ constexpr int MSTRIP_REC = 96;        // int32 per exchange record
 #ifndef DRNA_MKT_L
 #define DRNA_MKT_L 4
 #endif
-#ifndef DRNA_MKT_TOWER
-#define DRNA_MKT_TOWER 1
-#endif
-#ifndef DRNA_MKT_DEPTH
-#define DRNA_MKT_DEPTH 2
-#endif
-constexpr int MKT_W = DRNA_MKT_W, MKT_L = DRNA_MKT_L, MKT_TOWER = DRNA_MKT_TOWER, MKT_DEPTH = DRNA_MKT_DEPTH;
+constexpr int MKT_W = DRNA_MKT_W, MKT_L = DRNA_MKT_L;
+constexpr int MKT_DEPTH = 2;          // chunks of a tile step in flight (8 / 4 / 3 / 2 / 1 at 400 nt x 256: 4.80 / 4.68 / 4.52 / 4.46 / 4.58 ms)
 constexpr int MKT_BMIN = (44 + 2 * MKT_L + 15) / 16;          // smallest block distance with a far range
 static_assert(MKT_W >= 1 && MKT_W <= 16 && MKT_L >= 3, "see tools/pkt_schedule.py");
 
 // lane (row, n) of the 16-lane row: the value lane n of the same row holds (DPP row_newbcast on gfx90a and later)
 template <int N>
 __device__ __forceinline__ int row_bcast_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false); }
-__device__ __forceinline__ int lane_fetch_i32(int v, int src_lane) {
-#ifdef DRNA_EMU
-  return emu_exchange(v, src_lane);
-#else
-  return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);
-#endif
-}
 
 template <int NT>
 struct MfeStripSmem {
@@ -112,7 +95,7 @@ struct MfeStripSmem {
 
 template <typename RSRC>
 __device__ __forceinline__ i32x4 buf_load_i32x4_sc1(RSRC rsrc, int voff, int soff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, (STRIP_DIAG & 2) ? 0 : 16);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16);
   return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
 
@@ -127,7 +110,7 @@ __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j
 #pragma unroll
   for (int c = 0; c < NFX; c++) {
     fx[c] = INF_DEV;
-    if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+    if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, 16);
   }
   int m = INF_DEV;
 #pragma unroll
@@ -140,7 +123,7 @@ __device__ __forceinline__ void mstrip_f5_column(SM& sm, RSRC rsE, int ld, int j
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       gx[u] = INF_DEV;
-      if (cb + u < nch) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+      if (cb + u < nch) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, 16);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -173,7 +156,7 @@ __device__ __forceinline__ void mstrip_tower(SM& sm, int (&G)[GSLOTS], int d, in
   }
   const int accG = (MSTRIP_SKIP & 4) ? INF_DEV : mfe_tower_step(sm, G, par, i * 4, my_g, SM::NG, lane);
   if (live) atomicMin(&sm.accG[par][phys], accG);
-  if (!(STRIP_DIAG & 16) && has_down && live && iraw == 1) {
+  if (has_down && live && iraw == 1) {
     int32_t* rec = rec_out + (long long)d * MSTRIP_REC + 64 + my_g * GSLOTS;
 #pragma unroll
     for (int qx = 0; qx < GSLOTS; qx++) st_agent(rec + qx, (int32_t)G[qx]);
@@ -223,9 +206,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 
   // later rounds run only for sequences whose previous round found a pair (state word 1, written by the traceback kernel)
   if (round > 0 && Wc[0] != 1) return;
-#ifndef DRNA_EMU
-  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2] = wall_clock64();
-#endif
+  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2] = wall_clock_100mhz();
 
   // ---- prologue: tables
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
@@ -334,14 +315,6 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   if (wave == w_svcA) {
     const int d = TURN + 1;
     if (d < n_loc) mfe_prepare_tower_tab(sm, d, lane, ninio, max_ninio);
-#if MSTRIP_LEAD > 0
-    // let the strip above get MSTRIP_LEAD diagonals ahead before this one starts: both run at the same pace, so the lead stays,
-    // its flags are then always there when asked for and its records can be requested a step early (see service_a)
-    if (!(STRIP_DIAG & 4) && has_up && n_loc_up - 1 > TURN) {
-      int seen = 0;
-      (void)strip_wait(up_flag, lk.base, min(TURN + 1 + MSTRIP_LEAD, n_loc_up - 1), seen);
-    }
-#endif
   }
   if (wave == w_svcB) {
     const int d = TURN + 1;
@@ -489,7 +462,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     sa_g0 = ld_agent(rec + 64 + (lane & 31));                         // tower minima (30), fML, decomposition minimum
   };
   auto service_a = [&](const int k) {
-    const bool need = !(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1;
+    const bool need = has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1;
     if (need) {
       if (!sa_pend) {
         int seen = sa_f;
@@ -511,7 +484,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     }
     sa_pend = false;
     // one step ahead: the record of diagonal k, if the flag as last seen covers it; and the flag again
-    const bool next = !(STRIP_DIAG & 4) && has_up && k > TURN && k <= n_loc_up - 1;
+    const bool next = has_up && k > TURN && k <= n_loc_up - 1;
     if (next) {
       if (flag_ge(sa_f, lk.base + k) && sa_f != lk.base + STRIP_FAIL) { sa_request(k); sa_pend = true; }
       sa_f = __builtin_amdgcn_readfirstlane(ld_agent(up_flag));
@@ -535,7 +508,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 #pragma unroll
     for (int c = 0; c < NFX; c++) {
       fx[c] = INF;
-      if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+      if (c < nch) fx[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + c * WAVE) * 4, 0, 16);
     }
   };
   if (wave == w_svcB) sb_request(TURN + 1);
@@ -558,7 +531,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           gx[u] = INF;
-          if ((cb + u) * WAVE < fcnt) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, (STRIP_DIAG & 2) ? 0 : 16);
+          if ((cb + u) * WAVE < fcnt) gx[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, (j * ld + lane + 1 + (cb + u) * WAVE) * 4, 0, 16);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -573,17 +546,13 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     sb_request(k + 1);              // column k-2: its cells (diagonals <= k-3) were stored in step k-2 and drained by its barrier
   };
 
-  // ---- tile products of the blocked form (see MKT_L above and fold_pf_strip.hpp).  Tile waves (MKT_TOWER): the tower waves and
-  // the service waves, one tile row each -- a tower wave requests its chunks' operands, runs its tower step (LDS work) under their
-  // round trip and folds them in afterwards (tile_issue / tile_finish); else the floating and the service waves; the finalize waves
-  // of a workgroup that has neither.  At step k the tiles of block distance B = (k + 15 + MKT_W) >> 4 are in step
+  // ---- tile products of the blocked form (see MKT_L above and fold_pf_strip.hpp).  Tile waves: the tower waves and the service
+  // waves, one tile row each -- a tower wave requests its chunks' operands, runs its tower step (LDS work) under their round trip
+  // and folds them in afterwards (tile_issue / tile_finish); on the floating waves instead: 4.84 vs 4.46 ms at 400 nt x 256.  At step k the tiles of block distance B = (k + 15 + MKT_W) >> 4 are in step
   // g = (k + 15 + MKT_W) & 15 of their window (g < MKT_W).
-  constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * NG;
-  constexpr bool TILE_ON_TOWERS = MKT_TOWER != 0;
-  constexpr int NTW = TILE_ON_TOWERS ? NFIN * NG + NSVC : NFLOAT > 0 ? NFLOAT + NSVC : NFIN;
+  constexpr int NTW = NFIN * NG + NSVC;
   constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
-  const int tf = TILE_ON_TOWERS ? (aw >= 0 ? aw : NFIN * NG + wave - NFIN)
-                                : NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * NG : NFLOAT + wave - NFIN) : wave;
+  const int tf = aw >= 0 ? aw : NFIN * NG + wave - NFIN;
   int tacc[TOWN][4];
 #pragma unroll
   for (int o = 0; o < TOWN; o++) { tacc[o][0] = INF; tacc[o][1] = INF; tacc[o][2] = INF; tacc[o][3] = INF; }
@@ -614,7 +583,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     const int cid = c < q.nlo ? q.lo0 + c : q.nch - 1 - (q.hi0 + c - q.nlo);
     const int m0 = q.m_lo + 4 * cid, ma = m0 + (lane & 3), mb = m0 + (lane >> 4);
     a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, q.oA + min(ma, q.m_hi) * (ld * 4), 0, 0);
-    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, q.oB - min(mb, q.m_hi) * ((ld - 1) * 4), 0, (STRIP_DIAG & 2) ? 0 : 16);
+    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsF, q.oB - min(mb, q.m_hi) * ((ld - 1) * 4), 0, 16);
     if (ma > q.m_hi) a = INF;
     if (mb > q.m_hi) b = INF;
   };
@@ -727,7 +696,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
           const int fv = min(f, dec);
           sm.fmlrow[d & 1][i] = fv;
           strip_store(&FML[d * ld + ig], (int32_t)fv);
-          if (!(STRIP_DIAG & 16) && has_down && i <= 32) {
+          if (has_down && i <= 32) {
             int32_t* rec = rec_out + (long long)d * MSTRIP_REC;
             st_agent(rec + (i - 1), (int32_t)ww);
             st_agent(rec + 32 + (i - 1), (int32_t)cw);
@@ -737,7 +706,6 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
       MST(0);
-      if (!TILE_ON_TOWERS && NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       MST(1);
       STRIP_BARRIER();
@@ -758,7 +726,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   } else if (!pinned) {
     // ================= floating waves: tile products and items
     for (int k = TURN + 1; k <= n_loc; k++) {
-      if (k < n_loc) { if (!TILE_ON_TOWERS) tile_job(k); run_items(k, std::true_type{}); }
+      if (k < n_loc) run_items(k, std::true_type{});
       MST(1);
       STRIP_BARRIER();
       MST(2);
@@ -773,9 +741,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     static_assert(((TURN + 1) & 1) == 0, "the loop below starts on an even diagonal");
     for (int k = TURN + 1; k <= n_loc; k += 2) {
       if (k < n_loc) {
-        if (TILE_ON_TOWERS) tile_issue(k);
+        tile_issue(k);
         mstrip_tower(sm, GE, k, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
-        if (TILE_ON_TOWERS) tile_finish(k);
+        tile_finish(k);
         MST(0);
         run_items(k, std::false_type{});
         MST(1);
@@ -785,9 +753,9 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
       if (sm.sync_fail[k & 1]) { failed = true; break; }
       if (k + 1 > n_loc) break;
       if (k + 1 < n_loc) {
-        if (TILE_ON_TOWERS) tile_issue(k + 1);
+        tile_issue(k + 1);
         mstrip_tower(sm, GO, k + 1, wid, n_loc, phys, my_tb, my_g, lane, has_up, has_down, rec_out);
-        if (TILE_ON_TOWERS) tile_finish(k + 1);
+        tile_finish(k + 1);
         MST(0);
         run_items(k + 1, std::false_type{});
         MST(1);
@@ -809,9 +777,7 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
     }
     return;
   }
-#ifndef DRNA_EMU
-  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2 + 1] = wall_clock64();
-#endif
+  if (lk.clk && tid == 0) lk.clk[((long long)q * STRIP_MAXS + s) * 2 + 1] = wall_clock_100mhz();
   if (has_down) {
     if (tid == 0) st_agent(my_flag, lk.base + STRIP_DONE);
     return;
@@ -825,13 +791,8 @@ __device__ void mfe_strip_body(MfeStripSmem<NT>& sm, MfeArgs A, StripLink lk, St
   if (tid == 0) Wc[0] = 2;
 }
 
-#ifdef MSTRIP_WAVES8
-#define MSTRIP_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))     // 64 VGPRs: two workgroups per CU
-#else
-#define MSTRIP_ATTR
-#endif
 template <int NT, bool FARK>
-__global__ __launch_bounds__(NT) MSTRIP_ATTR void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
+__global__ __launch_bounds__(NT) void mfe_strip_kernel(MfeArgs A, StripLink lk, StripRec xr, int round) {
   __shared__ MfeStripSmem<NT> sm;
   const int b = blockIdx.x, per = 8 * (lk.S + lk.pad);
   const int grp = b / per, x = b - grp * per;

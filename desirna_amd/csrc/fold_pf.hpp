@@ -180,12 +180,6 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)QM, (short)0, (int)(2 * tab * 8), 0x00020000);
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)QBI, (short)0, (int)(tab * 8), 0x00020000);
 
-#ifdef DRNA_PHASECLK
-  long long pc_t[6] = {0, 0, 0, 0, 0, 0}, pc_last = wall_clock64();
-#define PCLK(k) do { const long long _n = wall_clock64(); pc_t[k] += _n - pc_last; pc_last = _n; } while (0)
-#else
-#define PCLK(k) do { } while (0)
-#endif
   for (int d = TURN + 1; d < n; d++) {
     const int ncell = n - d, par = d & 1;
     const int nblk = (ncell + WAVE - 1) / WAVE;
@@ -276,7 +270,6 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
         }
         accI += accG * sm.mmI[ij];
         sm.partI[item * WAVE + lane] = accI;
-        PCLK(0);
       } else {
         const int it = item - nI;
         const int b = it / H, h = it - b * H;
@@ -312,11 +305,9 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
           vA += stepA; vC -= stepC;
         }
         sm.partK[it * WAVE + lane] = acc0 + acc1;
-        PCLK(1);
       }
     }
     __syncthreads();
-    PCLK(2);
 
     for (int i = tid + 1; i <= ncell; i += NT) {
       const int b = (i - 1) / WAVE, ln = (i - 1) % WAVE;
@@ -350,17 +341,9 @@ __global__ __launch_bounds__(NT) void pf_kernel(PfArgs A) {
       DQ[at] = aK;
       QM[at] = m1 + aK + U;
     }
-    PCLK(3);
     if (wave == NW - 1 && d + 1 < n) pf_build_plist(sm, d + 1, n, lane);     // list of the next diagonal
-    PCLK(4);
     __syncthreads();
-    PCLK(5);
   }
-#ifdef DRNA_PHASECLK
-  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NW - 1 || wave == 5))
-    printf("pf_kernel wave %d: interior %lld K %lld barrierA %lld finalize %lld plist %lld barrierB %lld (100 MHz ticks)\n", wave,
-           pc_t[0], pc_t[1], pc_t[2], pc_t[3], pc_t[4], pc_t[5]);
-#endif
 
   // exterior: q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j)
   if (wave == 0) {

@@ -15,9 +15,6 @@
 //     diagonal.  Every partial sum has exactly one writer and is combined in a fixed order, so the
 //     result is bit-reproducible from run to run and independent of the batch composition.
 #pragma once
-#ifndef DRNA_JOIN_MASK
-#define DRNA_JOIN_MASK 0xF     // finalize waves that join the sweep's work queue once their own step is done
-#endif
 #include <cstddef>
 #include "eval_structure.hpp"
 #include "fold_pf.hpp"
@@ -151,17 +148,6 @@ __device__ __forceinline__ double pf_tower_step(const SM& sm, double (&G)[PGSLOT
 // of the entry's two constants, one add and two FMAs (the table-driven form this replaces: eight v_readlane, two adds and
 // four fp64 operations per entry, plus a table a finalize wave rebuilt every diagonal).  A wave owns the sizes of one parity
 // (s and s-2 must live in the same registers); rows of diagonals that do not exist yet read as zero (see PfFastSmem::qbi).
-// d = a * b + c with a destination of its own (the compiler prefers v_fmac + a copy)
-__device__ __forceinline__ double fma3_f64(double a, double b, double c) {
-#ifdef DRNA_EMU
-  return a * b + c;
-#else
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-#endif
-}
-
 template <class SM, int SIG, int Q0, int Q1>
 __device__ __forceinline__ void pf_tower2_part(const SM& sm, double (&G)[TSL], int dv, int i8, int cbase, double& acc) {
   const char* ring = reinterpret_cast<const char*>(sm.qbi);
@@ -208,16 +194,10 @@ __device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL],
 // (fma chains over x = row, row + 8 and x = row + 4, row + 12, added), far = sum over the kfar_subs(ncell) sub-sums in
 // order, each the fold (r0 + r1) + (r2 + r3) of four rows that walk their interleaved split points with two alternating
 // fma chains; D = near + far.
-#ifndef DRNA_KLAG
-#define DRNA_KLAG 12
-#endif
-#ifndef DRNA_KROUND
-#define DRNA_KROUND 4
-#endif
-constexpr int KLAG = DRNA_KLAG;
+constexpr int KLAG = 12;
 constexpr int KDF0 = 2 * KLAG - 1;      // first diagonal with a far split point
 constexpr int KNL = KLAG - 1 - (TURN + 1);   // near split points at either end
-constexpr int KROUND = DRNA_KROUND;     // diagonals per round of the helper
+constexpr int KROUND = 4;               // diagonals per round of the helper (8 is too coarse: 0.575 vs 0.532 ms; 2 no better)
 __host__ __device__ inline int kfar_sub_shift(int ncell) { return ncell > 96 ? 0 : ncell > 32 ? 1 : 2; }
 
 template <bool SC1, typename RS>
@@ -344,7 +324,7 @@ __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& 
     int itbase = 0;
     for (int dd = 0; dd <= dmax - d0; dd++) {
       const int d = d0 + dd, ncell = n - d, kfsh = kfar_sub_shift(ncell);
-      const int cnt = ((ncell + 31) >> 5) << kfsh;
+      const int cnt = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kfsh;      // (DRNA_SKIP: timing builds)
       for (int it = (wave + NW - itbase % NW) % NW; it < cnt; it += NW) {
         const int blk = it >> kfsh, sub = it & ((1 << kfsh) - 1), cl = lane & 15, row = lane >> 4;
         int i = (blk << 5) + 2 * cl + 1;
@@ -478,7 +458,6 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   // tower blocks, centred on the sequence
   const int NB = (n + WAVE - 1) / WAVE;
   const int off0 = (NB * WAVE - n) / 2;
-  const int NA = NW - NB;                  // sweep waves
   const int aw = wave - NB;                // index among the sweep waves (< 0: finalize wave)
   // Tower roles.  Generic loops exist from diagonal 10 on, where n - 10 cells are left: NBT = ceil((n - 10) / 64) blocks of 64 tower
   // slots starting at slot T0 cover them for the rest of the fill (the slot range only shrinks).  1024 threads: a block gets
@@ -541,7 +520,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     const int nblk = (ncell + 31) >> 5;
     const int F = d >= KDF0 ? d - 2 * KLAG + 2 : 0;            // far split points of this diagonal's cells
     const int kfsh = kfar_sub_shift(ncell);
-    const int nKf = ((DRNA_SKIP & 8) || hm || F == 0) ? 0 : nblk << kfsh;
+    const int nKf = ((DRNA_SKIP & (8 | 512)) || hm || F == 0) ? 0 : nblk << kfsh;      // (512: timing build without the far split points)
     const int nK = nKf + (((DRNA_SKIP & 8) || d < 2 * TURN + 3) ? 0 : nblk);
     const int nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2, nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
@@ -696,13 +675,10 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           // every producer writes its slot of every live cell on every diagonal it exists for, so nothing is zeroed here:
           // a family that does not exist yet (or a cell that cannot pair) is simply not read
           const int j = i + d;
-#ifndef DRNA_FVAR
-#define DRNA_FVAR 0      // diagnostic builds only (timing; results wrong): 1 no global stores, 2 no table lookups, 4 no sequence reads, 8 no partial-sum reads
-#endif
-          const int si = (DRNA_FVAR & 4) ? 2 : sm.S[i], sj = (DRNA_FVAR & 4) ? 1 : sm.S[j], si1 = (DRNA_FVAR & 4) ? 0 : sm.S[i + 1],
-                    sj1 = (DRNA_FVAR & 4) ? 3 : sm.S[j - 1], sim = (DRNA_FVAR & 4) ? 1 : sm.S[i - 1], sjp = (DRNA_FVAR & 4) ? 2 : sm.S[j + 1];
-          const double aG = (DRNA_FVAR & 8) ? 1e-3 : d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
-          const double aKn = (DRNA_FVAR & 8) ? 1e-3 : d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
+          const int si = sm.S[i], sj = sm.S[j], si1 = sm.S[i + 1],
+                    sj1 = sm.S[j - 1], sim = sm.S[i - 1], sjp = sm.S[j + 1];
+          const double aG = d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
+          const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
           double aKf = 0.0;
           if (hm) aKf = dfar_cur;
           else if (d >= KDF0) {                    // ((p0 + p1) + p2) + p3 with the sub-sums that exist (the others count as zero)
@@ -716,11 +692,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           const double tau = t > 2 ? eTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
-          const double aE = (DRNA_FVAR & 8) ? 1e-3 : sm.accE[par][tid], aX = (DRNA_FVAR & 8) ? 1e-3 : (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
-          const double wH = (DRNA_FVAR & 2) ? 0.5 : sm.mmH[ij], wI = (DRNA_FVAR & 2) ? 0.5 : sm.mmI[ij], wMc = (DRNA_FVAR & 2) ? 0.5 : sm.mmM[rt * 16 + sj1 * 4 + si1], wInfo = (DRNA_FVAR & 2) ? 0.5 : sm.mmI[info];
+          const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
+          const double wH = sm.mmH[ij], wI = sm.mmI[ij], wMc = sm.mmM[rt * 16 + sj1 * 4 + si1], wInfo = sm.mmI[info];
           const double dprev = sm.dring[((d - 2) & 3) * RS + i + 1];
           const int ex = t * 16 + sim * 4 + sjp;
-          const double wExt = (DRNA_FVAR & 2) ? 0.5 : sm.mmExt[ex], wMs = (DRNA_FVAR & 2) ? 0.5 : sm.mmM[ex], w5 = (DRNA_FVAR & 2) ? 0.5 : sm.d5[t * 4 + sim], w3 = (DRNA_FVAR & 2) ? 0.5 : sm.d3[t * 4 + sjp];
+          const double wExt = sm.mmExt[ex], wMs = sm.mmM[ex], w5 = sm.d5[t * 4 + sim], w3 = sm.d3[t * 4 + sjp];
           const int pp = (d - 1) & 1;
           const double m1p = sm.qm1row[pp][i], m1q = sm.qm1row[pp][i + 1], up = sm.urow[pp][i + 1];
           double qb = 0.0;
@@ -753,7 +729,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           sm.qm1row[par][i] = m1;
           sm.urow[par][i] = U;
           sm.dring[(d & 3) * RS + i] = aK;
-          if (!(DRNA_FVAR & 1)) {
+          {
             QEXT[j * ld + i] = ext;
             QM1[d * ld + i] = m1;
             QM[d * ld + i] = m1 + aK + U;
@@ -781,21 +757,13 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       }
       STAMP(4);
       TLMARK(1, k);
-      if (!(DRNA_SKIP & 128) && k < n && ((DRNA_JOIN_MASK >> wave) & 1)) run_items(k);          // help the sweep of diagonal k
+      if (!(DRNA_SKIP & 128) && k < n) run_items(k);          // help the sweep of diagonal k
       TLMARK(2, k);
       if (hm) { dfar_next = d_req; fb_last = __builtin_amdgcn_readfirstlane(f_req); }
-#ifdef DRNA_PF_LDSBAR
-      stores_in_flight<DRNA_PF_LDSBAR>();
-      lds_barrier();
-#else
       __syncthreads();
-#endif
       STAMP(3);
 #ifdef DRNA_STAMPS
       if (blockIdx.x == 0 && tid == 0) dbg[256 + k] = st_acc[4];
-#endif
-#ifdef DRNA_STEPCLK
-      if (blockIdx.x == DRNA_STEPCLK - 1 && tid == 0) reinterpret_cast<long long*>(base + 5 * tab)[k] = clock64();
 #endif
     }
   } else {
@@ -830,11 +798,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         STAMP(6);
         TLMARK(2, k);
       }
-#ifdef DRNA_PF_LDSBAR
-      lds_barrier();
-#else
       __syncthreads();
-#endif
       STAMP(3);
 #ifdef DRNA_STAMPS
       if (blockIdx.x == 0 && aw == 0 && lane == 0) dbg[512 + k] = st_last;

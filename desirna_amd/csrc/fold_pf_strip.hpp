@@ -52,24 +52,11 @@ namespace drna {
 #ifndef PSTRIP_SKIP
 #define PSTRIP_SKIP 0        // diagnostic builds only (timing; results wrong): 1 no multiloop items, 2 no bulge / 1xn items, 4 no small shapes, 8 no towers, 16 no tile products
 #endif
-#ifndef DRNA_PKT_OVERLAP
-#define DRNA_PKT_OVERLAP 0
-#endif
-constexpr bool PKT_OVERLAP = DRNA_PKT_OVERLAP != 0;     // 1: floating tile waves run the first item of the step between the tile loads and the products (measured: 36 spilled VGPRs, 1.72 vs 1.59 ms)
-#ifndef DRNA_PKT_TOWER
-#define DRNA_PKT_TOWER 0
-#endif
-constexpr int PKT_TOWER = DRNA_PKT_TOWER;               // 1: the tower (+ service) waves take the tile rows, their tower step under the loads (measured: 100 spilled VGPRs, 2.5 vs 1.57 ms at 400 nt; 1.9 with 3 chunks in flight)
-#ifndef DRNA_PKT_DEPTH
-#define DRNA_PKT_DEPTH 8
-#endif
-#ifndef DRNA_PKT_NB
-#define DRNA_PKT_NB 4
-#endif
-#ifndef DRNA_PKT_SVC
-#define DRNA_PKT_SVC 1
-#endif
-constexpr bool PKT_SVC = DRNA_PKT_SVC != 0;             // the service waves take tile rows too
+// (measured and dropped, DESIGN 3.8: tile rows on the tower waves with the tower step under the operands' round trip -- 100
+// spilled VGPRs, 2.5 vs 1.57 ms at 400 nt; the step's first item between a floating wave's tile loads and its products -- 36
+// spills, 1.72 vs 1.59 ms; tile rows on the floating waves only -- 1.61 vs 1.58 ms)
+constexpr int PKT_DEPTH = 8;                            // chunks of a tile step in flight (two loads each)
+constexpr int PKT_NB = 4;                               // near split points per lane and round trip
 #ifndef DRNA_PKT_W
 #define DRNA_PKT_W 16
 #endif
@@ -81,27 +68,6 @@ constexpr int PKT_L = DRNA_PKT_L;                       // the far range's opera
 constexpr int PKT_BMIN = PSTRIP_FARK ? (44 + 2 * PKT_L + 15) / 16 : (1 << 20);   // smallest block distance with a far range
 static_assert(PKT_W >= 1 && PKT_W <= 16, "tile windows must not overlap");
 static_assert(PKT_L >= 3, "a chunk must be final and visible when its step comes");
-
-#ifdef DRNA_EMU
-struct f64x4 { double v[4]; double& operator[](int k) { return v[k]; } double operator[](int k) const { return v[k]; } };
-// v_mfma_f64_16x16x4_f64 as the CDNA4 guide gives it: A[l & 15][l >> 4], B[l >> 4][l & 15], D[(l >> 4) + 4 r][l & 15] in register r
-__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
-  const int lane = threadIdx.x & 63, col = lane & 15;
-  for (int k = 0; k < 4; k++) {
-    const double bk = emu_exchange(b, col + 16 * k);
-    for (int r = 0; r < 4; r++) {
-      const double ak = emu_exchange(a, (lane >> 4) + 4 * r + 16 * k);
-      c.v[r] = std::fma(ak, bk, c.v[r]);
-    }
-  }
-  return c;
-}
-#else
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-#endif
 
 template <int NT>
 struct PfStripSmem {
@@ -160,7 +126,7 @@ __device__ __forceinline__ void strip_tower(SM& sm, double (&G)[PGSLOTS], int d,
   }
   const double accG = (PSTRIP_SKIP & 8) ? 0.0 : pf_tower_step(sm, G, par, i * 8, my_g, lane);
   if (live) sm.partG[par][my_g][phys] = accG;
-  if (!(STRIP_DIAG & 16) && has_down && live && iraw == 1) {               // the tower leaves the strip: its sums go into the record
+  if (has_down && live && iraw == 1) {               // the tower leaves the strip: its sums go into the record
     double* rec = rec_out + (long long)d * STRIP_REC + 48 + my_g * PGSLOTS;
 #pragma unroll
     for (int qx = 0; qx < PGSLOTS; qx++) st_agent(rec + qx, G[qx]);
@@ -322,7 +288,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
 
   // floating work items of diagonal d (see pf_lds_kernel): multiloop sums from L2 (the qm1 operand may be another strip's: sc1),
   // bulge / 1xn shapes, fixed small shapes.  Output slots are physical tower lanes (i_loc + d/2) mod P.
-  auto run_items = [&](const int d, auto with_k, int budget = 1 << 30) {
+  auto run_items = [&](const int d, auto with_k) {
     const int ncell = min(wid, n_loc - d), sh = d >> 1, par = d & 1;
     const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
     // near split points of the diagonal (tile geometry: see PKT_L): tt = m - 1 - i runs over [TURN+1, 28+PKT_L] and
@@ -349,7 +315,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
       }
       return nK + queue_pop(&sm.qe[par], lane);
     };
-    for (int it = budget > 0 ? pop() : nItems; it < nItems; it = --budget > 0 ? pop() : nItems) {
+    for (int it = pop(); it < nItems; it = pop()) {
       if (decltype(with_k)::value && it < nK) {
         const int g = (it & (KS - 1)) * 4 + (lane >> 4), cl = lane & 15;
         int i = ((it >> kssh) << 5) + 2 * cl + 1;
@@ -365,7 +331,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         f64x2 fv{0.0, 0.0};
         if (head && (far0 || far1)) fv = buf_load_f64x2_sc1(rsF, (d * ld + ig) * 8, 0);
         double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
-        constexpr int NB = DRNA_PKT_NB;        // terms per lane and round trip
+        constexpr int NB = PKT_NB;        // terms per lane and round trip
         for (int x = g; x < nterm; x += NB * KG) {
           f64x2 a[NB], c[NB];
           int tt[NB];
@@ -479,7 +445,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
   // A: wait for the strip above to have published diagonal k-1, stage its record (ring halo of row k-1, qm1 / U / D of its
   //    first column, the sums of the tower that enters at diagonal k+1); tower table of diagonal k+1
   auto service_a = [&](const int k) {
-    if (!(STRIP_DIAG & 4) && has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1) {
+    if (has_up && k - 1 > TURN && k - 1 <= n_loc_up - 1) {
       int seen = 0;
       if (!strip_wait(up_flag, lk.base, k - 1, seen)) {
         sm.sync_fail[k & 1] = 1;
@@ -558,21 +524,17 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     }
   };
 
-  // ---- tile products (see PKT_L above).  Tile waves (PKT_TOWER): the tower waves and the service waves, one tile row each --
-  // a tower wave requests its chunks' operands, runs its tower step (LDS work) under their round trip and multiplies afterwards
-  // (tile_issue / tile_finish); else the floating (+ service) waves; the finalize waves of a workgroup that has neither.  Tile wave
+  // ---- tile products (see PKT_L above).  Tile waves: the floating and the service waves, one tile row each (the finalize waves of a
+  // workgroup that has neither); a tile wave requests its chunks' operands (tile_issue) and multiplies (tile_finish).  Tile wave
   // f owns the tile rows f, f + NTW, ...  At step k the tiles of block distance B = (k + 15 + PKT_W) >> 4 are in step
   // g = (k + 15 + PKT_W) & 15 of their window (g < PKT_W; k = d_min - PKT_W + g): operands on diagonals <= d_min - PKT_L <= k - 2.
   constexpr int NFLOAT = NW - NFIN - NSVC - NFIN * PNG;
-  constexpr bool TILE_ON_TOWERS = PKT_TOWER != 0;
-  constexpr int NTW = TILE_ON_TOWERS ? NFIN * PNG + NSVC : NFLOAT > 0 ? NFLOAT + (PKT_SVC ? NSVC : 0) : NFIN;
+  constexpr int NTW = NFLOAT > 0 ? NFLOAT + NSVC : NFIN;
   constexpr int TOWN = ((SM::WMAX + 15) / 16 + NTW - 1) / NTW;
-  const int tf = TILE_ON_TOWERS ? (aw >= 0 ? aw : NFIN * PNG + wave - NFIN)
-                                : NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * PNG : NFLOAT + wave - NFIN) : wave;
+  const int tf = NFLOAT > 0 ? (aw >= 0 ? aw - NFIN * PNG : NFLOAT + wave - NFIN) : wave;
   f64x4 tacc[TOWN];
 #pragma unroll
   for (int o = 0; o < TOWN; o++) tacc[o] = f64x4{0.0, 0.0, 0.0, 0.0};
-  constexpr int PKT_DEPTH = DRNA_PKT_DEPTH;              // chunks in flight (two loads each)
   double tq_a[TOWN][PKT_DEPTH], tq_b[TOWN][PKT_DEPTH];   // operands requested by tile_issue
   struct TileStep { int t, bj, m_lo, m_hi, nch, lo0, nlo, hi0, ncs, oA, oB; bool on; };
   auto tile_step = [&](const int k, const int o, int& g) -> TileStep {
@@ -717,7 +679,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
           sm.dring[(d & 3) * RS + i] = aK;
           strip_store(&QM1[d * ld + ig], m1);
           QM[d * ld + ig] = m1 + aK + U;
-          if (!(STRIP_DIAG & 16) && has_down && i <= 32) {                          // the record for the strip below
+          if (has_down && i <= 32) {                          // the record for the strip below
             double* rec = rec_out + (long long)d * STRIP_REC;
             st_agent(rec + (i - 1), qv);
             st_agent(reinterpret_cast<int*>(rec + 32) + (i - 1), info);
@@ -726,7 +688,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
         }
       }
       if (!NSVC && wave == 0) { service_a(k); service_b(k); }
-      if (!TILE_ON_TOWERS && NFLOAT == 0 && k < n_loc) tile_job(k);
+      if (NFLOAT == 0 && k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});            // help the sweep of diagonal k
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
@@ -735,7 +697,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     // ================= service waves
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (wave == w_svcA) service_a(k); else service_b(k);
-      if ((PKT_SVC || TILE_ON_TOWERS) && k < n_loc) tile_job(k);
+      if (k < n_loc) tile_job(k);
       if (k < n_loc) run_items(k, std::true_type{});
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
@@ -744,8 +706,7 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     // ================= floating waves: items only
     for (int k = TURN + 1; k <= n_loc; k++) {
       if (k < n_loc) {
-        if (!TILE_ON_TOWERS && PKT_OVERLAP) { tile_issue(k); run_items(k, std::true_type{}, 1); tile_finish(k); }   // one item under the tile operands' round trip
-        else if (!TILE_ON_TOWERS) tile_job(k);
+        tile_job(k);
         run_items(k, std::true_type{});
       }
       STRIP_BARRIER();
@@ -764,18 +725,14 @@ __device__ void pf_strip_body(PfStripSmem<NT>& sm, PfArgs A, StripLink lk, int q
     static_assert(((TURN + 1) & 1) == 0, "the loop below starts on an even diagonal");
     for (int k = TURN + 1; k <= n_loc; k += 2) {
       if (k < n_loc) {
-        if (TILE_ON_TOWERS) tile_issue(k);
         tower(k, GE);
-        if (TILE_ON_TOWERS) tile_finish(k);
         run_items(k, std::false_type{});
       }
       STRIP_BARRIER();
       if (sm.sync_fail[k & 1]) { failed = true; break; }
       if (k + 1 > n_loc) break;
       if (k + 1 < n_loc) {
-        if (TILE_ON_TOWERS) tile_issue(k + 1);
         tower(k + 1, GO);
-        if (TILE_ON_TOWERS) tile_finish(k + 1);
         run_items(k + 1, std::false_type{});
       }
       STRIP_BARRIER();

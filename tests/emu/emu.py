@@ -13,10 +13,10 @@ _CSRC = os.path.join(_HERE, "..", "..", "desirna_amd", "csrc")
 def build(flags=(), tag=""):
     """flags: extra -D options (a build of its own, libemu<tag>.so): experimental code paths of the kernels"""
     lib = _LIB if not tag else _LIB.replace(".so", tag + ".so")
-    srcs = [os.path.join(_HERE, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("emu_kernels.cpp", "hip_emu.h", "hip_emu_prims.h")]
     srcs += [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hpp")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread"] + list(flags) + ["-o", lib,
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", _HERE] + list(flags) + ["-o", lib,
                                os.path.join(_HERE, "emu_kernels.cpp")])
     L = C.CDLL(lib)
     vp, ci = C.c_void_p, C.c_int

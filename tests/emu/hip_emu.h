@@ -4,7 +4,9 @@
 // time: every GPU thread is an OS thread, __syncthreads() is a real barrier, wave collectives
 // (__shfl_xor, __ballot) rendezvous the 64 lanes of a wave.  Nothing here is part of the product.
 #pragma once
-#define DRNA_EMU 1
+// the kernels' hardware primitives (desirna_amd/csrc/gfx950_prims.hpp) are replaced by the stand-ins of hip_emu_prims.h: the one
+// hook the product headers offer (fold_common.hpp); g++ is given -I tests/emu
+#define DRNA_PRIMS_HEADER "hip_emu_prims.h"
 #include <sched.h>
 #include <pthread.h>
 #include <stdint.h>

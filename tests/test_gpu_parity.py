@@ -557,8 +557,9 @@ def test_config4_full_size_3200_sequences(oracle, eterna_solutions):
 
 def test_config5_full_size_R128_L400_pk_alts_edef(eng400, oracle, eterna_targets):
     """Config 5 as stated: L=400 target, R=128, pk heuristic, two alternative targets and the ensemble defect, all in one
-    test on one engine: properties on all 128 entries, 6 entries against the oracle (a 400-mer with up to four fills
-    takes the oracle a good fraction of a second)."""
+    test on one engine: properties on all 128 entries, 32 entries (every fourth, and both ends of the two sequence classes)
+    against the oracle -- MFE structure with its pseudoknot layers, energies, Epf, E(target and alternatives), ensemble defect;
+    the oracle's 32 x (up to four fills + inside + outside) run on its worker threads."""
     from desirna_amd import engine as E
     tg = eterna_targets["eteV1_53.txt"]
     alts = [eterna_targets["eteV1_22.txt"], eterna_targets["eteV1_63.txt"]]
@@ -581,13 +582,21 @@ def test_config5_full_size_R128_L400_pk_alts_edef(eng400, oracle, eterna_targets
         # the pk-annotated string's '(' ')' layer is the unconstrained MFE structure: its energy is the MFE energy
         if k < 12:
             assert oracle.eval_structure(seqs[k], plain) == int(out["Emfe"][k])
-    for k in (0, 1, 60, 119, 120, 127):
+    picks = sorted(set(list(range(0, 116, 4)) + [119, 120, 127]))        # 29 + 3
+    assert len(picks) == 32
+
+    def check(k):
         ss, e = oracle.mfe(seqs[k])
         assert out["mfe_ss"][k] == oracle.pk_struct(seqs[k], ss) and int(out["Emfe"][k]) == e
         assert abs(float(out["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE
         for t, st in enumerate([tg] + alts):
             assert int(out["Ed"][k, t]) == oracle.eval_structure(seqs[k], st)
         assert abs(ed[k] - oracle.ensemble_defect(seqs[k], tg)) < 1e-10
+        return k
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:          # the oracle's C calls release the GIL (ctypes)
+        assert sorted(pool.map(check, picks)) == picks
 
 
 def test_pf_range_error_code():
@@ -874,6 +883,12 @@ def test_batches_larger_than_the_workspace_go_in_chunks(eng400, oracle, monkeypa
         a = small.score_batch(uni, flags)
         b = eng400.score_batch(uni, flags)
         assert a["mfe_ss"] == b["mfe_ss"] and (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all()
+        # the ensemble defect goes through the same workspaces: more sequences than slots in sub-batches (advisor r3: it used to
+        # return an argument error, which aborted a native Monte-Carlo run with an Edef term at its first defect call)
+        tg130 = "((((....))))" + "." * 118
+        small.set_targets([tg130]); eng400.set_targets([tg130])
+        ea, eb = small.ensemble_defect(uni), eng400.ensemble_defect(uni)
+        assert (ea.view(np.int64) == eb.view(np.int64)).all() and abs(ea[-1] - oracle.ensemble_defect(uni[-1], tg130)) < 1e-10
     finally:
         small.close()
     k = 4
@@ -896,3 +911,59 @@ def test_bench_exchange_step_over_rccl_single_rank():
     line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
     d = json.loads(line)
     assert d["collectives"] == "nccl" and d["n_gpus"] == 1 and d["metric"] and d["value"] > 0
+
+
+def test_bench_line_carries_parity_roofline_baseline_and_the_monte_carlo_loop():
+    """The driver's own run in small: `bench.py --steps 3 --warmup 1` WITH the CPU baseline must end in one JSON line whose
+    timed device buffers were checked against the oracle (parity_checked), with the roofline of the dominant kernel, the CPU
+    baseline beside it, and the end-to-end Monte-Carlo loop figure (reference utils/replica_exchange_monte_carlo.py:176-210)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DRNA_BENCH_BACKEND", "DRNA_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--exchange-every", "20"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["parity_checked"] is True and d["parity"]["Emfe_Ed_structures"] == "bit-exact" and d["parity"]["max_abs_dEpf"] < 1e-9
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["sync_fallbacks"] == 0
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "lds", "valu") and 0.0 < rf["frac"] <= 1.0 and rf["traffic"] > 0 and rf["own_floor"]["floor_ms"] > 0
+    assert d["achieved_hbm_GB_s"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1
+    mc = d["mc_loop"]
+    assert mc["scored_sequences_per_s"] > 0 and mc["iterations"] == 20 and mc["replicas"] == 64 and mc["L"] == 200
+    assert mc["ms_per_iteration"] >= mc["kernel_ms_per_iteration"] > 0 and mc["accepted"] + mc["rejected"] == 20 * 64
+    assert "workgroups <= " in d["cus_occupied"]["resident_check"]
+
+
+def test_one_launch_form_equals_the_two_launches(eng400, oracle, eterna_targets):
+    """Option "fused": both folds of a small batch in ONE launch of 4 R workgroups (fold_fused.hpp; off by default: measured
+    0.5 % slower).  Same device functions, so every output is bit for bit that of the two launches; odd batch sizes leave idle
+    blocks at the end of the grid; pseudoknot rounds run inside the MFE roles."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(4141)
+    tg = eterna_targets["eteV1_69.txt"]
+    for L, R, pk in ((200, 64, False), (200, 63, True), (180, 5, False)):
+        t = tg[:L] if L == 200 else "." * L
+        seqs = [_rand(rng, L) for _ in range(R)]
+        eng400.set_targets([t])
+        flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL | (E.NEED_PK if pk else 0)
+        a = eng400.score_batch(seqs, flags)
+        assert eng400.get_option("last_fused") == 0
+        eng400.set_option("fused", 1)
+        try:
+            b = eng400.score_batch(seqs, flags)
+            assert eng400.get_option("last_fused") == 1 and eng400.get_option("last_workgroups") == 4 * R
+            c = eng400.score_batch(seqs, flags)
+        finally:
+            eng400.set_option("fused", 0)
+        for x in (b, c):
+            assert x["mfe_ss"] == a["mfe_ss"] and (x["Emfe"] == a["Emfe"]).all() and (x["Ed"] == a["Ed"]).all()
+            assert (x["Epf"].view(np.int64) == a["Epf"].view(np.int64)).all()
+        tm = eng400.last_timing()
+        assert 0 < tm["mfe"] <= tm["total"] * 1.05 and 0 < tm["pf"] <= tm["total"] * 1.05
+        ss, e = oracle.mfe(seqs[0])
+        assert (a["mfe_ss"][0] == (oracle.pk_struct(seqs[0], ss) if pk else ss)) and int(a["Emfe"][0]) == e

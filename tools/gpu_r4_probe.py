@@ -53,17 +53,22 @@ if "sweep" in sys.argv[1:] or len(sys.argv) == 1:
             eng.close()
 
 if "variants" in sys.argv[1:] or len(sys.argv) == 1:
-    sq = seqs_for(64)
+    VR = int(os.environ.get("VAR_R", "64"))
+    vflags = {"both": E.NEED_PF | E.NEED_MFE | E.NEED_EVAL, "pf": E.NEED_PF, "mfe": E.NEED_MFE}[os.environ.get("VAR_FLAGS", "both")]
+    sq = seqs_for(VR)
     for lib in sorted(glob.glob(os.path.join(ROOT, "build", "var", "lib_*.so"))):
         name = os.path.basename(lib)[4:-3]
-        for fused in (1, 0):
-            eng = E.Engine(max_R=64, max_L=L, lib=lib)
+        for fused in ((1, 0) if VR <= 64 and os.environ.get("VAR_FUSED", "both") == "both" else (int(os.environ.get("VAR_FUSED", "1")),)):
+            eng = E.Engine(max_R=VR, max_L=L, lib=lib)
             eng.set_targets([tg])
             try:
                 eng.set_option("fused", fused)
             except Exception:
                 pass
-            r = time_batch(eng, sq, E.NEED_PF | E.NEED_MFE | E.NEED_EVAL, reps=40)
+            try:
+                r = time_batch(eng, sq, vflags, reps=int(os.environ.get("VAR_REPS", "40")))
+            except Exception as ex:                       # timing builds leave phases out: results (and status words) may be off
+                r = {"error": str(ex)[:80], **eng.last_timing()}
             out["var_%s_fused%d" % (name, fused)] = r
             print("variant %-20s fused %d" % (name, fused), r, "fallbacks", eng.get_option("sync_fallbacks"), flush=True)
             eng.close()

@@ -1,4 +1,4 @@
-"""Collect the rocprofv3 PMC passes / floor build written by tools/gpu_round2.sh under gpurun_out/ into
+"""Collect the rocprofv3 PMC passes / floor build written by tools/gpu_round4.sh under gpurun_out/ into
 gpurun_out/roofline_inputs.json (per-launch averages for the fold kernels of the L=200, R=64 benchmark batch, plus the
 calibration kernels that fix the counters' units).  Copy to profiles/roofline_inputs.json once the kernels are final:
 bench.py reads it from there."""
@@ -16,6 +16,7 @@ def counters(prefix, name):
 
 
 def key_of(kname):
+    if "score_fused" in kname: return "fused"
     if "mfe" in kname: return "mfe"
     if "pf_" in kname: return "pf"
     if "eval" in kname: return "eval"
@@ -68,15 +69,17 @@ try:
             stats[key_of(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
 except FileNotFoundError:
     pass
-try:
-    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-except Exception:
-    head = "?"
+head = os.environ.get("DRNA_COMMIT")        # the GPU box's snapshot has no .git: tools/gpu_round4.sh is started with the hash
+if not head:
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        sys.exit("roofline_inputs.py: no commit to record (set DRNA_COMMIT: the counters must name the source they were taken from)")
 # the guide (MI355X_MICROARCH.md, LDS): a conflict-free ds_read_b64 / ds_read_b32 wave-instruction takes 2 LDS-array cycles;
 # the measured counter value per such instruction converts SQ_LDS_IDX_ACTIVE to LDS-array cycles
 lds_unit = 2.0 / units["SQ_LDS_IDX_ACTIVE_per_ds_read_b64"] if units.get("SQ_LDS_IDX_ACTIVE_per_ds_read_b64") else 1.0
 valu_unit = 4.0 / units["SQ_ACTIVE_INST_VALU_per_v_add"] if units.get("SQ_ACTIVE_INST_VALU_per_v_add") else 4.0
-out = {"source": "tools/gpu_round3.sh pmc+floor passes at %s; per-launch averages, R=64 x L=200 uniform batch" % head,
+out = {"source": "tools/gpu_round4.sh pmc + floor passes at commit %s; per-launch averages, R=64 x L=200 uniform batch" % head, "commit": head,
        "units": units, "lds_cycles_per_count": lds_unit, "valu_cycles_per_count": valu_unit, "raw": {}, "kernels": {}}
 GW = grid_workgroups()
 for k, d in raw.items():
@@ -99,6 +102,7 @@ for k, d in raw.items():
     if 15 in floor:
         e["floor_ms"] = floor[15][key] if key in floor[15] else None
         e["full_ms_same_run"] = floor.get(0, {}).get(key)
+        e["floor_build"] = "-DDRNA_SKIP=15 of the production launch configuration (tools/phase_cost.py): %s" % k
     if key in stats:
         e["rocprof_avg_ms"] = stats[key]["avg_ns"] * 1e-6
     e["clock_hz"] = 2.4e9
