@@ -245,7 +245,7 @@ static void launch_mfe_strips_round(drna_engine* e, const MfeArgs& a, int nseq, 
   if (lk.fark) hipLaunchKernelGGL((mfe_strip_kernel<1024, true>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
   else hipLaunchKernelGGL((mfe_strip_kernel<1024, false>), dim3(groups * 8 * (S + strip_pad(S))), dim3(1024), 0, st, a, lk, xr, round);
   if (after_fill) (void)hipEventRecord(after_fill, st);
-  hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(WAVE), 0, st, a, idx, nseq, round, r0);
+  hipLaunchKernelGGL(mfe_strip_trace_kernel, dim3(nseq), dim3(TRACE_WAVES * WAVE), 0, st, a, idx, nseq, round, r0);
 }
 // MFE fold of nseq sequences by S strips each: per pseudoknot round one launch of the fill and one of the traceback
 static void launch_mfe_strips(drna_engine* e, const MfeArgs& a, int nseq, int S, int first_slot, const int* idx, hipStream_t st) {

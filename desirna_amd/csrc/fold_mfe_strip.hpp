@@ -9,7 +9,7 @@
 // fML cannot stay in LDS here (the multiloop splits read all of it): it goes to the sequence's table 2 in HBM/L2 like the
 // general kernel's, stored write-through, and the split items read it from there (16 bytes = four adjacent cells per lane).
 // A pseudoknot round is ONE launch of the fill (mfe_strip_kernel) followed by ONE launch of the traceback
-// (mfe_strip_trace_kernel, one wave per sequence, on the tables the strips left in HBM): the kernel boundary is the hand-over,
+// (mfe_strip_trace_kernel, eight waves per sequence, on the tables the strips left in HBM): the kernel boundary is the hand-over,
 // the structure found so far (the output string itself) is the state that masks the next round.
 #pragma once
 #include "fold_mfe_lds.hpp"
@@ -801,16 +801,23 @@ __global__ __launch_bounds__(NT) void mfe_strip_kernel(MfeArgs A, StripLink lk, 
   mfe_strip_body<NT, FARK>(sm, A, lk, xr, q, s, round);
 }
 
-// traceback of one round, one wave per sequence, on the tables the strips of that round left in HBM (a launch of its own: the
-// kernel boundary makes them visible).  State word Wc[0]: 2 = the fill of this round is done (written by the last strip),
-// -1 = a strip lost its neighbour; this kernel leaves 1 if another round follows for the sequence, else 0.
-struct MfeTraceSmem : MfeSmemCore<STRIP_NMAX> {};
+// traceback of one round, one workgroup of TRACE_WAVES waves per sequence, on the tables the strips of that round left in HBM (a
+// launch of its own: the kernel boundary makes them visible).  The waves work from one queue of sectors in LDS (TbShared,
+// fold_mfe.hpp: exterior stems and multiloop branches are independent), as the LDS-resident kernels' traceback does since
+// round 3; round 3's one wave per sequence took 0.18-0.22 ms per round at 400 nt.  State word Wc[0]: 2 = the fill of this round
+// is done (written by the last strip), -1 = a strip lost its neighbour; this kernel leaves 1 if another round follows for the
+// sequence, else 0.
+constexpr int TRACE_WAVES = 8;
+struct MfeTraceSmem : MfeSmemCore<STRIP_NMAX> {
+  int tbq[4];                    // sector queue of the traceback (TbShared)
+};
 
 __device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const int* idx, int q, int round, int r0 = 0) {
+  constexpr int NT = TRACE_WAVES * WAVE;
   const int r = idx ? idx[q] : q + r0;
   if (A.rg.len) A.L = A.rg.len[r];
   const long long so = A.rg.off ? (long long)A.rg.off[r] : (long long)r * A.L;
-  const int n = A.L, ld = A.ld, lane = lane_id();
+  const int n = A.L, ld = A.ld, tid = threadIdx.x;
   const MfeTables& T = *A.T;
   int32_t* base = A.ws + (long long)r * A.ws_stride;
   const long long tab = (long long)ld * ld;
@@ -818,17 +825,18 @@ __device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const i
   const int32_t* FML = base + 2 * tab;
   const int32_t* EXT = base + 4 * tab;
   const int state = Wc[0];
-  if (round > 0 && state != 2) return;                 // no fill this round: the sequence was finished earlier
-  for (int k = lane; k < 64; k += WAVE) sm.stack[k] = T.stack[k];
-  for (int k = lane; k < 128; k += WAVE) {
+  if (round > 0 && state != 2) return;                 // no fill this round: the sequence was finished earlier (workgroup-uniform)
+  for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
+  for (int k = tid; k < 128; k += NT) {
     sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
     sm.mm23[k] = T.mm23[k]; sm.mmM[k] = T.mmM[k]; sm.mmExt[k] = T.mmExt[k];
   }
-  for (int k = lane; k < 1024; k += WAVE) sm.int11[k] = T.int11[k];
-  for (int k = lane; k < 32; k += WAVE) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
-  if (lane == 0) sm.flag = 0;
+  for (int k = tid; k < 1024; k += NT) sm.int11[k] = T.int11[k];
+  for (int k = tid; k < 32; k += NT) { sm.d5[k] = T.d5[k]; sm.d3[k] = T.d3[k]; }
+  if (tid == 0) sm.flag = 0;
+  __syncthreads();
   const char* seq = A.seqs + so;
-  for (int k = lane; k < n; k += WAVE) {
+  for (int k = tid; k < n; k += NT) {
     const int c = enc_nt(seq[k]);
     if (c < 0) sm.flag = 1;
     sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c);
@@ -837,45 +845,52 @@ __device__ inline void mfe_strip_trace_body(MfeTraceSmem& sm, MfeArgs A, const i
     sm.Sp[k + 1] = (unsigned char)(c < 0 || prev != '.' ? 4 : c);
     sm.ssw[k] = '.';
   }
-  for (int k = lane; k <= n; k += WAVE) sm.f5[k] = Wc[ld + k];
-  if (lane == 0) { sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; sm.Sp[0] = 4; sm.Sp[n + 1] = 4; }
+  for (int k = tid; k <= n; k += NT) sm.f5[k] = Wc[ld + k];
+  for (int k = tid; k < (int)(sizeof(sm.sec_ml) / sizeof(sm.sec_ml[0])); k += NT) sm.sec_ml[k] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    sm.S[0] = sm.S[n]; sm.S[n + 1] = sm.S[1]; sm.Sp[0] = 4; sm.Sp[n + 1] = 4;
+    sm.sec_i[0] = 1; sm.sec_j[0] = (short)n; sm.sec_ml[0] = 1;          // entry 0 = the whole exterior interval (ml 0), published
+    sm.tbq[0] = 0; sm.tbq[1] = 1; sm.tbq[2] = 1; sm.tbq[3] = 0;
+  }
   __syncthreads();
   if (sm.flag) {
-    if (lane == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; Wc[0] = 0; }
-    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = '.';
+    if (tid == 0) { A.status[r] = ST_BAD_CHAR; A.Emfe[r] = 0; Wc[0] = 0; }
+    for (int k = tid; k < n; k += NT) A.ss[so + k] = '.';
     return;
   }
   if (state != 2) {                                    // round 0 and the fill failed (ST_SYNC is already in the status word)
-    if (lane == 0) { A.Emfe[r] = 0; Wc[0] = 0; }
-    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = '.';
+    if (tid == 0) { A.Emfe[r] = 0; Wc[0] = 0; }
+    for (int k = tid; k < n; k += NT) A.ss[so + k] = '.';
     return;
   }
-  const bool ok = mfe_traceback(sm, A, Wc, FmlGlobal{FML, ld}, EXT);
+  (void)mfe_traceback_q(sm, A, Wc, FmlGlobal{FML, ld}, EXT, TbShared<MfeTraceSmem>{sm});
   __syncthreads();
-  if (!ok) {
-    if (lane == 0) { A.status[r] = ST_TRACEBACK; Wc[0] = 0; if (round == 0) A.Emfe[r] = sm.f5[n]; }
-    for (int k = lane; k < n; k += WAVE) A.ss[so + k] = sm.sspk[k];
+  if (sm.tbq[3] == 2) {                                // a wave could not reproduce a table value
+    if (tid == 0) { A.status[r] = ST_TRACEBACK; Wc[0] = 0; if (round == 0) A.Emfe[r] = sm.f5[n]; }
+    for (int k = tid; k < n; k += NT) A.ss[so + k] = sm.sspk[k];
     return;
   }
   const char op = round == 0 ? '(' : round == 1 ? '[' : round == 2 ? '<' : '{';
   const char cl = round == 0 ? ')' : round == 1 ? ']' : round == 2 ? '>' : '}';
   int any = 0;
-  for (int k = lane; k < n; k += WAVE) {
+  for (int k = tid; k < n; k += NT) {
     const char ch = sm.ssw[k];
     if (ch == '(') { sm.sspk[k] = op; any = 1; }
     else if (ch == ')') sm.sspk[k] = cl;
     A.ss[so + k] = sm.sspk[k];
   }
-  const bool any_w = __ballot(any != 0) != 0ull;
-  if (lane == 0) {
+  if (any) sm.flag = 2;
+  __syncthreads();
+  if (tid == 0) {
     if (round == 0) A.Emfe[r] = sm.f5[n];
     A.status[r] = ST_OK;
     // reference sequence_utils.py:1194,1210: the next re-fold happens only if this one found a pair
-    Wc[0] = ((round == 0 || any_w) && round < A.pk_rounds) ? 1 : 0;
+    Wc[0] = ((round == 0 || sm.flag == 2) && round < A.pk_rounds) ? 1 : 0;
   }
 }
 
-__global__ __launch_bounds__(WAVE) void mfe_strip_trace_kernel(MfeArgs A, const int* idx, int nseq, int round, int r0) {
+__global__ __launch_bounds__(TRACE_WAVES * WAVE) void mfe_strip_trace_kernel(MfeArgs A, const int* idx, int nseq, int round, int r0) {
   __shared__ MfeTraceSmem sm;
   if ((int)blockIdx.x >= nseq) return;
   mfe_strip_trace_body(sm, A, idx, blockIdx.x, round, r0);

@@ -99,7 +99,7 @@ static void run_mfe_strip(const MfeArgs& a, int R, int S, int calls, int fark) {
           });
         emu_launch_many(r * S, NT, fns);
       }
-      for (int r = 0; r < R; r++) emu_launch(r, 64, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round, 0); });
+      for (int r = 0; r < R; r++) emu_launch(r, TRACE_WAVES * WAVE, [&, r, round]() { mfe_strip_trace_body(*smt, a, nullptr, r, round, 0); });
     }
   for (auto* p : sms) delete p;
   delete smt;
