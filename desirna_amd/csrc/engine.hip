@@ -727,6 +727,12 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     HIP_TRY(hipEventRecord(e->ev_e1, s_ev));
     return DRNA_OK;
   };
+  static const bool host_profile = getenv("DRNA_HOST_PROFILE") != nullptr;      // diagnostics: where a call's host time goes (stderr, every 64 calls)
+  static double hp_acc[4] = {0, 0, 0, 0};
+  static int hp_n = 0;
+  auto hp_now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  const double hp0 = host_profile ? hp_now() : 0.0;
+  double hp1 = 0.0, hp2 = 0.0;
   if (!use_fused) {
   if (mfe_first) { const int rc = enqueue_mfe(); if (rc != DRNA_OK) return rc; }
   if (want_ev && s_ev == e->s_pf) { const int rc = enqueue_eval(); if (rc != DRNA_OK) return rc; }
@@ -737,10 +743,12 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // join on the host: the streams are drained one after the other (a device-side join -- stream-wait-event packets
   // plus an end marker -- costs ~15 us after the last kernel); "total" = first start event to the latest end event
   auto drain = [&](hipStream_t st) -> hipError_t { return hipStreamSynchronize(st); };
+  if (host_profile) hp1 = hp_now();
   if (want_ev && !ev_in_pf && s_ev == e->s_eval) HIP_TRY(drain(e->s_eval));
   if (mfe_first && want_pf) HIP_TRY(drain(e->s_pf));
   if (want_mfe) HIP_TRY(drain(e->s_mfe));
   if (!mfe_first && want_pf) HIP_TRY(drain(e->s_pf));
+  if (host_profile) hp2 = hp_now();
   e->timing[0] = e->timing[1] = e->timing[2] = 0.f;
   if (want_mfe) HIP_TRY(hipEventElapsedTime(&e->timing[0], e->ev_m0, e->ev_m1));
   if (want_pf) HIP_TRY(hipEventElapsedTime(&e->timing[1], e->ev_p0, e->ev_p1));
@@ -754,6 +762,15 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->timing[3] = tot;
     for (int k = 0; k < 4; k++) e->timing_sum[k] += e->timing[k];
     e->timing_sum[4] += 1.0;
+  }
+  if (host_profile) {
+    const double hp3 = hp_now();
+    hp_acc[0] += hp1 - hp0; hp_acc[1] += hp2 - hp1; hp_acc[2] += hp3 - hp2; hp_acc[3] += e->timing[3] * 1e3;
+    if (++hp_n == 64) {
+      fprintf(stderr, "drna_score_batch_device: host us per call: enqueue %.1f, drain %.1f (device %.1f), event queries %.1f\n",
+              hp_acc[0] / 64, hp_acc[1] / 64, hp_acc[3] / 64, hp_acc[2] / 64);
+      hp_n = 0; hp_acc[0] = hp_acc[1] = hp_acc[2] = hp_acc[3] = 0;
+    }
   }
   }   // !use_fused
   for (int r = 0; r < R; r++) {
