@@ -479,6 +479,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   const bool pinned = aw >= 0 && my_tb < NB;
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;
+  // the shape table of the next diagonal goes to a wave of its own when there is one without a side job (n > 128: wave 2): with
+  // both tables on wave 1 that wave was the last to reach the barrier in two steps of three (tools/timeline.py: +1.84 us against
+  // +1.33 for the cell finalize alone)
+  const int w_et = NB > 3 ? 2 : w_tab;
 
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
@@ -701,7 +705,8 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
       // <= k-4, were stored in step <= k-3 and had landed by the end of step k-2)
       if (k + 1 < n) {
-        if (wave == w_tab) mfe_prepare_tables<NT>(sm, k + 1, lane, ninio, max_ninio, DUAL ? E_NEAR : E_ALL);
+        if (wave == w_tab) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
+        if (wave == w_et) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
         if (wave == w_pl) {
           const int dn = k + 1;
           int* dst = sm.plist[dn & 1];
