@@ -602,6 +602,18 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     int pfK = INF, pfI = INF, fb_s = 0;
     bool have = false;
     if (DUAL) fb_s = __builtin_amdgcn_readfirstlane(ld_agent(lk.flagB));
+    // the staged list row travels in registers from the step that requests it to the next one (wave w_pl)
+    int pw[4] = {0, 0, 0, 0}, px[4] = {0, 0, 0, 0}, pw_cnt = 0;
+    auto pl_request = [&](const int dn) {
+      const int32_t* row = PL + dn * ld;
+      const int32_t* rowx = PLX + dn * ld;
+      pw_cnt = row[ld - 1];
+      const int nch = (n - dn + WAVE - 1) >> 6;                 // chunks the diagonal's cells can fill (uniform, known without the count)
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (c < nch) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
+    };
+    if (wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       MTLMARK(0, k);
@@ -620,18 +632,24 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         rqI = ld_agent(rq_on ? xi + (d + 1) * XP + i2 : lk.flagB);
         rqF = ld_agent(lk.flagB);
       }
-      // ---- top of the step: requests of the pipelined side jobs
-      // (the list row of diagonal k+1 and the exterior column's cells are requested here and consumed after the cell
-      // finalize, so that their L2 round trip overlaps it)
-      int pw[4] = {0, 0, 0, 0}, px[4] = {0, 0, 0, 0}, pw_cnt = 0, fx[4];
-      if (wave == w_pl && k + 1 < n) {
-        const int32_t* row = PL + (k + 1) * ld;
-        const int32_t* rowx = PLX + (k + 1) * ld;
-        pw_cnt = row[ld - 1];
-        const int nch = (n - (k + 1) + WAVE - 1) >> 6;          // chunks the diagonal's cells can fill (uniform, known without the count)
+      // ---- top of the step: the pipelined side jobs.  The list row of diagonal k+1 was requested a whole step ago (the rows were
+      // written by the prologue and have left the L2 by now: they come from HBM, and with the request at the top of the SAME step
+      // the wave that stages them reached the barrier last in every early step -- tools/timeline.py: +2.46 us against +1.66 for
+      // the cell finalize); it goes into LDS here -- the sweep waves read the other parity's buffer -- and the row of diagonal
+      // k+2 is requested into the same registers.  The exterior column's cells are requested here and consumed after the cell
+      // finalize.
+      int fx[4];
+      if (wave == w_pl) {
+        if (k + 1 < n) {
+          const int dn = k + 1;
+          int* dst = sm.plist[dn & 1];
+          int* dxe = sm.xe[dn & 1];
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-          if (c < nch) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
+          for (int c = 0; c < 4; c++)
+            if (lane + c * WAVE < MfeFastSmem<NT>::NL) { dst[lane + c * WAVE] = pw[c]; dxe[lane + c * WAVE] = px[c]; }
+          if (lane == 0) { sm.pcnt[dn & 1] = pw_cnt; sm.qhead[dn & 1] = 0; }
+        }
+        if (k + 2 < n) pl_request(k + 2);
       }
       if (wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
@@ -707,15 +725,6 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       if (k + 1 < n) {
         if (wave == w_tab) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
         if (wave == w_et) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
-        if (wave == w_pl) {
-          const int dn = k + 1;
-          int* dst = sm.plist[dn & 1];
-          int* dxe = sm.xe[dn & 1];
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-            if (lane + c * WAVE < MfeFastSmem<NT>::NL) { dst[lane + c * WAVE] = pw[c]; dxe[lane + c * WAVE] = px[c]; }
-          if (lane == 0) { sm.pcnt[dn & 1] = pw_cnt; sm.qhead[dn & 1] = 0; }
-        }
       }
       if (wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
