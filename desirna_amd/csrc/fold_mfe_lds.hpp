@@ -719,12 +719,17 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           }
         }
       }
+      MTLMARK(1, k);
       // side jobs of the step, one finalize wave each (when there are that many): tower table and pairable list of
       // diagonal k+1 (the sweep waves are reading those of diagonal k), exterior column j = k-3 (its cells, diagonals
       // <= k-4, were stored in step <= k-3 and had landed by the end of step k-2)
       if (k + 1 < n) {
-        if (wave == w_tab) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
-        if (wave == w_et) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
+        // once the outermost tower blocks hold no cell any more (n = 200: from diagonal 72 on) their finalize waves, which keep the
+        // list staging and the exterior column, are done long before the centre blocks' (+0.9 against +1.6 us): the tables go to them
+        const bool outer_idle = NB > 3 && (d >> 1) + off0 >= WAVE;
+        const int wt = outer_idle ? 0 : w_tab, we = outer_idle ? NB - 1 : w_et;
+        if (wave == wt) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
+        if (wave == we) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
       }
       if (wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
@@ -739,7 +744,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         if (lane == WAVE - 1) sm.f5[j] = prev < m ? prev : m;
       }
       STAMP(4);
-      MTLMARK(1, k); MTLMARK(2, k);
+      MTLMARK(2, k);
       // every global load of the step has been consumed; what is still in flight are this step's stores (c, exterior term,
       // and the two published words of the two-workgroup kernel): the wait lets exactly those stay in flight across the
       // barrier, so the stores of the PREVIOUS step have landed -- which is what their readers rely on (exterior column
@@ -788,8 +793,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         // balanced whatever their tower load: first the 16-cell multiloop sub-blocks (K), then pairs of
         // pairable cells for the 112 bulge / 1xn shapes and the nine small fixed shapes (E).  Minima are order-free,
         // so who takes what does not matter.
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5,      // two-workgroup kernel: the edge split points only
-                  nE = (DRNA_SKIP & 2) ? 0 : DUAL ? 2 * ((pcnt + WAVE - 1) >> 6) : (pcnt + 3) >> 2;
+        // one-workgroup kernel: a 32-cell block's split points go to 1, 2 or 4 items as the cells get fewer and the sums longer (a late
+        // diagonal has two or three blocks and 190 split points: as one item per block three waves walked ~1.5 us chains while nine
+        // idled; minima are order-free, so the split does not show in the results: 0.566 -> 0.555 ms at R = 64, 0.579 -> 0.565 at R = 128).
+        // In the helper of the two-workgroup kernel the same split gains nothing and finer ones lose (0.477 -> 0.487 / 0.500 ms).
+        // Two-workgroup kernel, main role: the edge split points only, one item per block
+        const int kssh = DUAL ? 0 : ncell > 128 ? 0 : ncell > 64 ? 1 : 2;
+        const int k_per = (((d - 2 * TURN - 2 + (1 << kssh) - 1) >> kssh) + 3) & ~3;      // split points per item (TURN+1 .. d-TURN-2)
+        const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh,
+                  nE = (DRNA_SKIP & 2) ? 0 : DUAL ? e_items_per_block<E_NEAR>() * ((pcnt + WAVE - 1) >> 6) : (pcnt + 3) >> 2;
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
         // one-workgroup kernel: items from the work queue (LDS counter).  Main role of the two-workgroup kernel: the few
         // items left (edge split points, near shapes) are dealt statically, waves of the outer tower blocks -- whose towers
@@ -799,7 +811,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           STAMP(6);
           if (it < nK) {
             if (DUAL) mfe_k_edge_item(sm, it, d, n, ncell, par, slot0, lane);
-            else mfe_k_item(sm, it, d, n, ncell, par, slot0, lane, TURN + 1, d - TURN - 2);
+            else {
+              const int lo = TURN + 1 + (it & ((1 << kssh) - 1)) * k_per;
+              mfe_k_item(sm, it >> kssh, d, n, ncell, par, slot0, lane, lo, min(d - TURN - 2, lo + k_per - 1));
+            }
             STAMP(5);
 #ifdef DRNA_STAMPS
             st_acc[7]++;
