@@ -9,8 +9,8 @@
 //   * generic interior loops by register-resident tower sums (2 LDS reads per live inner diagonal);
 //   * bulges and 1xn loops one PAIRABLE cell at a time with the 112 shapes spread over the lanes and a
 //     DPP wave sum; the nine fixed small shapes by one wave per 64 pairable cells;
-//   * multiloop sums from L2: a wave takes 16 cells x 4 interleaved split-point groups, 16 loads in
-//     flight per lane;
+//   * multiloop sums: the far split points of a 4 x 4 tile of cells as one matrix product (v_mfma_f64_4x4x4_4b_f64),
+//     the near ones per cell from L2, a wave takes 32 cells x 4 rows of slots;
 //   * finalize waves (one lane per cell) run one diagonal behind the sweep waves: one barrier per
 //     diagonal.  Every partial sum has exactly one writer and is combined in a fixed order, so the
 //     result is bit-reproducible from run to run and independent of the batch composition.
@@ -44,7 +44,6 @@ struct PfFastSmem {
   double q5[PF_FAST_NMAX + 2];
   double partG[2][2][NSLOT];      // tower sums, one slice per parity of the loop size
   double partK[2][4][NSLOT];      // multiloop sums, near split points: one slice per row
-  double partF[2][4][NSLOT];      // far split points (when no helper workgroup computes them): one slice per sub-sum
   double accE[2][NSLOT], accX[2][3][NSLOT];   // accX: one slice per group of fixed shapes
   // Boltzmann tables
   double stack[64], mmH[128], mmI[128], mm1n[128], mm23[128], mmM[128], mmExt[128], int11[1024], d5[32], d3[32];
@@ -53,11 +52,14 @@ struct PfFastSmem {
   double r1n[128];                // expMismatch1nI(info) / expMismatchI(info)
   double r23[128];                // expMismatch23I(info) / expMismatchI(info)
   double eWt[36][2];              // E items, by loop size t: {bulge[t] scale[t+2], interior[t] eninio[t-2] scale[t+2] (1xn loops, t >= 4)}; 0 beyond 30
-  double xc[8];                   // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items)
+  double xc[16];                  // weights of the fixed small shapes: bulge-1, 2x3, scale^4, scale^5, scale^6 (read by the X items);
+                                  // 8..: TermAU, MLclosing, MLintern, expMLbase, scale^2: the cell finalize reads its constants here
+                                  // (held in registers over the loop they cost spills on the finalize waves' critical path)
   double twc[32][2];              // by total size s of a generic loop: {eninio[s - 4], interior[s] scale[s + 2] (0 below s = 6)}
   int plist[2][NL];               // pairable cells of the diagonal: i | ij << 8
   int pcnt[2];
   int qhead[2];                   // work-queue head of the diagonal's floating items
+  int qtile[2];                   // ... of its tile products (sweep waves only)
   unsigned char info[32 * RS];    // zero-initialised like qbi
   unsigned char S[PF_FAST_NMAX + 4];
   int flag;
@@ -183,79 +185,158 @@ __device__ __forceinline__ double pf_tower2_step(const SM& sm, double (&G)[TSL],
 }
 
 
-// ---- multiloop sums D[i,j] = sum_tt qm[i,i+tt] qm1[i+tt+1,j], tt = TURN+1 .. d-TURN-2, in ONE canonical order (round 3).
-// The split points of a cell are cut into a NEAR part -- the KLAG - 5 first and the KLAG - 5 last, whose longer operand is
-// younger than KLAG diagonals -- and a FAR part (both operands at least KLAG diagonals old, tt = KLAG-1 .. d-KLAG, from
-// diagonal KDF0 on).  The far part needs nothing recent, so in small batches a HELPER workgroup on an idle CU computes it
-// from rows the main workgroup publishes (pf_kfar_helper) and the main workgroup, whose vector-memory path the multiloop
-// operands saturate (21 MB per fold through 64 B/clk: 0.15 of 0.58 ms), keeps 14 split points per cell.  Without a helper
-// the main workgroup works the far part itself, through the same functions and in the same order, so Epf does not depend on
-// which way a batch was run: per cell, near = (r0 + r1) + (r2 + r3) over four interleaved rows of at most four split points
-// (fma chains over x = row, row + 8 and x = row + 4, row + 12, added), far = sum over the kfar_subs(ncell) sub-sums in
-// order, each the fold (r0 + r1) + (r2 + r3) of four rows that walk their interleaved split points with two alternating
-// fma chains; D = near + far.
-constexpr int KLAG = 12;
-constexpr int KDF0 = 2 * KLAG - 1;      // first diagonal with a far split point
-constexpr int KNL = KLAG - 1 - (TURN + 1);   // near split points at either end
-constexpr int KROUND = 4;               // diagonals per round of the helper (8 is too coarse: 0.575 vs 0.532 ms; 2 no better)
-__host__ __device__ inline int kfar_sub_shift(int ncell) { return ncell > 96 ? 0 : ncell > 32 ? 1 : 2; }
+// ---- multiloop sums D[i,j] = sum_m qm[i,m-1] qm1[m,j], m = i+TURN+2 .. j-TURN-1, in ONE canonical order (round 4).
+// Cells are grouped in TILES of 4 columns i x 4 columns j: tile row a = (i-1) >> 2, tile column c = (j-1) >> 2, block distance
+// B = c - a; the tile's cells lie on the diagonals 4B-3 .. 4B+3.  The split points
+//        m_lo = 4a + 9 + PKE  <=  m  <=  4c - 3 - PKE = m_hi                       (the FAR range of the tile: 4B - 11 - 2 PKE of them)
+// have, for EVERY cell of the tile, both operands on diagonals <= 4B - 5 - PKE, i.e. final PKE + 2 diagonals before the tile's
+// first cell is due.  Their part of the sum is a 4 x (m_hi - m_lo + 1) x 4 matrix product: ONE wave computes it with
+// v_mfma_f64_4x4x4_4b_f64 -- the instruction's four independent blocks take the split points m_lo + 16 u + 4 block + k, so one
+// instruction consumes sixteen of them for all sixteen cells (two 8-byte loads per 256 terms; per-cell sums need two 16-byte
+// loads per 2 terms) --, two alternating accumulator chains over u, the four blocks added by two DPP steps:
+// far = ((D3 + D2) + (D1 + D0)) of (even u) + (odd u).  What is left per cell is the NEAR part: at most PKE + 3 split points at
+// either end of its range (all of them in tiles without a far range, B < KT_BMIN), in 4 rows of KT_U slots -- slot s of the
+// cell is its s-th split point from below (s < KT_NL) or its (s - KT_NL)-th from above; row s & 3 walks its slots with two
+// alternating fma chains; near = (r0 + r1) + (r2 + r3); D = near + far.
+// The far part needs nothing recent, so in small batches a HELPER workgroup on an idle CU computes it from rows the main
+// workgroup publishes (pf_kfar_helper), one block distance per round; without a helper (large batches: every CU holds a fold)
+// the main workgroup's own item queue takes the tiles of block distance B during the four steps before their first cell is due.
+// Either way the same device function runs the same instructions on the same operands: Epf does not depend on how a batch was run.
+// (Round 3 walked the far part per cell: 16 bytes per term, which on a full chip is 4.4 GB per launch from beyond the L2 --
+// R = 256 ran the fold in 0.83 ms against 0.60 on a quarter of the chip.)
+#ifndef DRNA_PKE
+#define DRNA_PKE 5
+#endif
+constexpr int PKE = DRNA_PKE;                       // slack of the far range, in diagonals (>= 4: the main workgroup's own window)
+constexpr int KT_NL = PKE + 3;                      // near split points at either end of a cell's range, at most
+constexpr int KT_U = (2 * KT_NL + 3) / 4;           // near slots per row
+constexpr int KT_BMIN = (12 + 2 * PKE + 3) / 4;     // smallest block distance with a far range
+constexpr int KT_D0 = 4 * KT_BMIN - 3;              // first diagonal with a far split point
+constexpr int KT_MF = (4 * ((PF_FAST_NMAX - 1) / 4) - 11 - 2 * PKE + 15) / 16;   // products of the longest far range
+#ifndef DRNA_KT_DEPTH
+#define DRNA_KT_DEPTH 3
+#endif
+constexpr int KT_DEPTH = DRNA_KT_DEPTH;             // products of a tile in flight
+static_assert(PKE >= 4, "a tile's operands must be final when the first of its four steps comes");
 
-template <bool SC1, typename RS>
-__device__ __forceinline__ f64x2 k_load2(RS rs, int voff, int soff) {
-  if (SC1) return buf_load_f64x2_sc1(rs, voff, soff);
-  return buf_load_f64x2(rs, voff, soff);
+// near split points of cell (i, i+d): nl from below, nh from above
+__device__ __forceinline__ void kt_near_counts(int i, int d, int& nl, int& nh) {
+  const int j = i + d, a = (i - 1) >> 2, c = (j - 1) >> 2, tot = max(d - 2 * TURN - 2, 0);
+  if (c - a >= KT_BMIN) { nl = 4 * a + 4 + PKE - i; nh = j - 4 * c - 1 + PKE; }
+  else { nl = min(tot, KT_NL); nh = tot - nl; }
 }
+__device__ __forceinline__ bool kt_has_far(int i, int d) { return ((i + d - 1) >> 2) - ((i - 1) >> 2) >= KT_BMIN; }
 
-// far sub-sum: row `g` of KGf interleaved rows, cells i and i+1 of diagonal d (operands: table at byte 0 = qm, at tab8 = qm1)
-template <bool SC1, typename RS>
-__device__ __forceinline__ void k_far_row(RS rs, int tab8, int ld, int d, int i, int g, int KGf, double& v0, double& v1) {
-  double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;       // cell i: p0 + p1, cell i+1: q0 + q1
-  int tt = KLAG - 1 + g;
-  const int tmax = d - KLAG;
-  const int astep = 8 * KGf * ld, cstep = 8 * KGf * (ld - 1);
-  // byte offsets: qm[i, i+tt] at (tt ld + i) 8, qm1[i+tt+1, j] at tab8 + ((d-tt-1) ld + i+tt+1) 8; a step of KGf in tt moves them
-  // by +8 KGf ld and -(8 KGf ld - 8 KGf)
-  int vA = (tt * ld + i) * 8;
-  int vC = tab8 + ((d - tt - 1) * ld + i + tt + 1) * 8;
-  for (; tt + 3 * KGf <= tmax; tt += 4 * KGf) {
-    const int vCl = vC - 3 * cstep;                                       // operand of tt + 3 KGf: in range here
-    const f64x2 a0 = k_load2<SC1>(rs, vA, 0), c0 = k_load2<SC1>(rs, vCl, 3 * cstep);
-    const f64x2 a1 = k_load2<SC1>(rs, vA, astep), c1 = k_load2<SC1>(rs, vCl, 2 * cstep);
-    const f64x2 a2 = k_load2<SC1>(rs, vA, 2 * astep), c2 = k_load2<SC1>(rs, vCl, cstep);
-    const f64x2 a3 = k_load2<SC1>(rs, vA, 3 * astep), c3 = k_load2<SC1>(rs, vCl, 0);
-    vA += 4 * astep; vC -= 4 * cstep;
-    p0 = fma(a0.x, c0.x, p0); q0 = fma(a0.y, c0.y, q0); p1 = fma(a1.x, c1.x, p1); q1 = fma(a1.y, c1.y, q1);
-    p0 = fma(a2.x, c2.x, p0); q0 = fma(a2.y, c2.y, q0); p1 = fma(a3.x, c3.x, p1); q1 = fma(a3.y, c3.y, q1);
-  }
-  for (; tt <= tmax; tt += KGf) {
-    const f64x2 a0 = k_load2<SC1>(rs, vA, 0), c0 = k_load2<SC1>(rs, vC, 0);
-    p0 = fma(a0.x, c0.x, p0); q0 = fma(a0.y, c0.y, q0);
-    vA += astep; vC -= cstep;
-  }
-  v0 = p0 + p1; v1 = q0 + q1;
-}
-
-// near part: row `row` of four takes the split points x = row, row + 4, row + 8, row + 12 of the near list
-// (x < KNL: tt = TURN+1 + x; else tt = TURN+1 + x + F, F = number of far split points in between)
+// near part: row `row` of four, cells i and i+1 of diagonal d (one 16-byte load fetches an operand of both: they share the
+// split point's distance tt = m - 1 - i; a slot that only one of them owns counts as zero for the other)
 template <typename RS>
-__device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i, int row, int F, double& v0, double& v1) {
-  const int Nn = d - 2 * (TURN + 1) - F;
-  f64x2 a[4], c[4];
+__device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i, int row, double& v0, double& v1) {
+  int nl0, nh0, nl1, nh1;
+  kt_near_counts(i, d, nl0, nh0);
+  kt_near_counts(i + 1, d, nl1, nh1);
+  f64x2 a[KT_U], c[KT_U];
 #pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int x = row + 4 * u;
-    const bool ok = x < Nn;
-    const int xx = ok ? x : 0;
-    const int tt = TURN + 1 + xx + (xx >= KNL ? F : 0);
+  for (int u = 0; u < KT_U; u++) {
+    const int s = row + 4 * u, y = s - KT_NL;
+    const bool low = s < KT_NL;
+    const bool ok0 = low ? s < nl0 : y < nh0, ok1 = low ? s < nl1 : y < nh1;
+    int tt = low ? TURN + 1 + s : d - TURN - 2 - y;
+    tt = (ok0 || ok1) ? tt : TURN + 1;
     a[u] = buf_load_f64x2(rs, (tt * ld + i) * 8, 0);
     c[u] = buf_load_f64x2(rs, tab8 + ((d - tt - 1) * ld + i + tt + 1) * 8, 0);
-    if (!ok) { a[u].x = 0.0; a[u].y = 0.0; c[u].x = 0.0; c[u].y = 0.0; }
+    if (!ok0) a[u].x = 0.0;
+    if (!ok1) a[u].y = 0.0;
   }
-  const double p0 = fma(a[2].x, c[2].x, fma(a[0].x, c[0].x, 0.0)), p1 = fma(a[3].x, c[3].x, fma(a[1].x, c[1].x, 0.0));
-  const double q0 = fma(a[2].y, c[2].y, fma(a[0].y, c[0].y, 0.0)), q1 = fma(a[3].y, c[3].y, fma(a[1].y, c[1].y, 0.0));
+  double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < KT_U; u++) {
+    if (u & 1) { p1 = fma(a[u].x, c[u].x, p1); q1 = fma(a[u].y, c[u].y, q1); }
+    else { p0 = fma(a[u].x, c[u].x, p0); q0 = fma(a[u].y, c[u].y, q0); }
+  }
   v0 = p0 + p1; v1 = q0 + q1;
 }
 
+// far part of tile (a, a + B): operands from the table at byte 0 (qm) and at tab8 (qm1) of `rs`.  Two halves: k_tile_issue
+// requests the operands of the last product and of the first KT_PRE (two 8-byte loads per product: a lane's addresses advance
+// by wave-uniform strides of 16 split points, which the buffer instructions take as a scalar offset; only the last product
+// clamps and masks), k_tile_finish multiplies, fetches what a long far range has beyond that KT_DEPTH products at a time, and
+// hands the sixteen sums to store(d, i, v).
+#ifndef DRNA_KT_PRE
+#define DRNA_KT_PRE 3
+#endif
+constexpr int KT_PRE = DRNA_KT_PRE < KT_MF - 1 ? DRNA_KT_PRE : KT_MF - 1;
+struct KTile {
+  double al, bl, av[KT_PRE], bv[KT_PRE];
+  int vA, vB;                // a lane's operand addresses (product 0 of qm, the last but one of qm1)
+  int a, c, last;            // (wave-uniform)
+  bool mask_last;
+};
+template <bool SC1, typename RS>
+__device__ __forceinline__ void k_tile_issue(RS rs, int tab8, int ld, int n, int a, int B, int lane, KTile& t) {
+  const int c = a + B, m_lo = 4 * a + 9 + PKE, m_hi = 4 * c - 3 - PKE;
+  const int last = __builtin_amdgcn_readfirstlane((m_hi - m_lo + 16) >> 4) - 1;
+  const int q = lane & 3, moff = (lane & 12) + (lane >> 4);
+  const int i = 4 * a + 1 + q, jc = min(4 * c + 1 + q, n);         // a column beyond the sequence repeats the last one: its sums are not stored
+  // qm[i, m-1] at ((m - 1 - i) ld + i) 8, qm1[m, j] at tab8 + ((j - m) ld + m) 8; product u takes m = m_lo + moff + 16 u
+  const int sA = 16 * ld * 8, sB = 16 * (ld - 1) * 8;                                      // bytes per product (qm1 walks downwards)
+  const int m0 = m_lo + moff, ml = min(m0 + 16 * last, m_hi);                              // the last product's split point, clamped
+  const int vA = (i - (1 + i) * ld + m0 * ld) * 8;                                         // + u sA
+  const int vB = tab8 + (jc * ld - (m0 + 16 * last) * (ld - 1)) * 8;                        // + (last - u) sB
+  const int vAl = (i - (1 + i) * ld + ml * ld) * 8, vBl = tab8 + (jc * ld - ml * (ld - 1)) * 8;
+  t.a = a; t.c = c; t.last = last; t.mask_last = m0 + 16 * last > m_hi; t.vA = vA; t.vB = vB;
+#pragma unroll
+  for (int u = 0; u < KT_PRE; u++) {
+    if (u < last) {
+      t.av[u] = SC1 ? buf_load_f64_aux(rs, vA, u * sA) : buf_load_f64(rs, vA, u * sA);
+      t.bv[u] = SC1 ? buf_load_f64_aux(rs, vB, (last - u) * sB) : buf_load_f64(rs, vB, (last - u) * sB);
+    }
+  }
+  t.al = SC1 ? buf_load_f64_aux(rs, vAl, 0) : buf_load_f64(rs, vAl, 0);
+  t.bl = SC1 ? buf_load_f64_aux(rs, vBl, 0) : buf_load_f64(rs, vBl, 0);
+}
+template <bool SC1, typename RS, typename ST>
+__device__ __forceinline__ void k_tile_finish(RS rs, int ld, const KTile& t, int n, int lane, ST store) {
+  const int sA = 16 * ld * 8, sB = 16 * (ld - 1) * 8, last = t.last;
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < KT_PRE; u++) {
+    if (u < last) {
+      if (u & 1) acc1 = mfma_f64_4x4x4_4b(t.av[u], t.bv[u], acc1);
+      else acc0 = mfma_f64_4x4x4_4b(t.av[u], t.bv[u], acc0);
+    }
+  }
+#pragma unroll
+  for (int u0 = KT_PRE; u0 < KT_MF - 1; u0 += KT_DEPTH) {
+    if (u0 < last) {
+      double av[KT_DEPTH], bv[KT_DEPTH];
+#pragma unroll
+      for (int w = 0; w < KT_DEPTH; w++) {
+        const int u = u0 + w;
+        if (u < last && u < KT_MF - 1) {
+          av[w] = SC1 ? buf_load_f64_aux(rs, t.vA, u * sA) : buf_load_f64(rs, t.vA, u * sA);
+          bv[w] = SC1 ? buf_load_f64_aux(rs, t.vB, (last - u) * sB) : buf_load_f64(rs, t.vB, (last - u) * sB);
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < KT_DEPTH; w++) {
+        const int u = u0 + w;
+        if (u < last && u < KT_MF - 1) {
+          if (u & 1) acc1 = mfma_f64_4x4x4_4b(av[w], bv[w], acc1);
+          else acc0 = mfma_f64_4x4x4_4b(av[w], bv[w], acc0);
+        }
+      }
+    }
+  }
+  // (the last product joins the chain its index belongs to: the order of the sums does not depend on the cut)
+  const double al = t.mask_last ? 0.0 : t.al;
+  if (last & 1) acc1 = mfma_f64_4x4x4_4b(al, t.bl, acc1);
+  else acc0 = mfma_f64_4x4x4_4b(al, t.bl, acc0);
+  double v = acc0 + acc1;
+  v = dpp_add_f64<0x114, 0xF>(v);          // row_shr:4, row_shr:8: the lanes of block 3 end with ((D3 + D2) + (D1 + D0))
+  v = dpp_add_f64<0x118, 0xF>(v);
+  const int ii = 4 * t.a + 1 + (lane >> 4), jj = 4 * t.c + 1 + (lane & 3);
+  if ((lane & 12) == 12 && jj <= n) store(jj - ii, ii, v);
+}
 // Diagnostic builds only (-DDRNA_SKIP=mask, tools/phase_cost.py): leave out a sweep phase to read its marginal cost
 // from the kernel time (results are wrong by construction).  1 = T, 2 = E, 4 = X, 8 = K, 16 = cell finalize, 32 = table / pairable-list
 // preparation, 64 = exterior column.
@@ -267,9 +348,11 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 #ifdef DRNA_TL
 #define TLMARK(ev, k) do { if (tl_on && lane == 0) tl[((wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
 #define TLMARK2(ev, k) do { if (tl_on && lane == 0) tl[((48 + wave * 3 + (ev)) << 8) + (k)] = (long long)wall_clock64(); } while (0)
+#define TLMARK3(k) do { if (tl_on && lane == 0) tl[((60 + wave) << 8) + (k)] = (long long)wall_clock64(); } while (0)     // sweep waves: tile products done
 #else
 #define TLMARK(ev, k) do { } while (0)
 #define TLMARK2(ev, k) do { } while (0)
+#define TLMARK3(k) do { } while (0)
 #endif
 #ifndef STAMP
 #ifdef DRNA_STAMPS
@@ -279,14 +362,15 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 #endif
 #endif
 
-// ---- helper workgroup of pf_lds_kernel (small batches: idle CUs): the FAR multiloop split points of every cell, from the
+// ---- helper workgroup of pf_lds_kernel (small batches: idle CUs): the FAR multiloop split points of every tile, from the
 // rows the main workgroup publishes.  Hand-over as the CDNA4 guide prescribes (and as fold_mfe_dual.hpp does it): payload by
 // sc1 stores into tables of its own (XQM, XQM1: tables 0 and 1 of the sequence's workspace, which this kernel does not use
 // otherwise -- the main workgroup's own reads stay on plain-stored QM / QM1, whose lines remain in its L2), every storing wave
 // drained, workgroup barrier, ONE lane stores the flag; the consumer polls the flag from one wave and loads the payload
-// only afterwards, sc1.  One-way slack instead of a per-step round trip: diagonal d needs rows <= d - KLAG only and is due
-// KLAG steps after the last of them, so the helper works KROUND diagonals per round (enough items for sixteen waves, one set
-// of barriers) and stays ahead of the main workgroup's need by itself.  Results travel back through DFAR (table 5).
+// only afterwards, sc1.  One-way slack instead of a per-step round trip: the tiles of block distance B need rows <= 4B - 5 - PKE
+// only and their first cell is due at diagonal 4B - 3, so a round (one block distance: up to 44 tiles for sixteen waves) starts
+// PKE steps before its results are asked for.  Results travel back through DFAR (table 5); the flag says up to which diagonal
+// every cell has its far sum.
 template <int NT>
 __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& EV, PfFastSmem<NT>& sm, int r, int n) {
   constexpr int NW = NT / WAVE;
@@ -298,9 +382,7 @@ __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& 
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)(2 * tab * 8), 0x00020000);     // XQM, XQM1
   const int* flagA = A.hflags + (long long)r * 64;
   int* flagB = A.hflags + (long long)r * 64 + 32;
-  double* part = reinterpret_cast<double*>(&sm);              // [KROUND][4][256] sub-sums by cell (the ring is not used here)
-  int* ctl = reinterpret_cast<int*>(part + KROUND * 4 * 256);
-  for (int k = tid; k < KROUND * 4 * 256; k += NT) part[k] = 0.0;
+  int* ctl = reinterpret_cast<int*>(&sm);                     // (the ring is not used here)
   if (tid == 0) ctl[0] = 0;
   // E(target structures) of this sequence (eval_structure.hpp), while the main workgroup works towards the first far split point:
   // a launch of its own would need CUs of its own, and in the batches that get a helper every CU holds a fold workgroup
@@ -311,47 +393,24 @@ __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& 
       for (int k = wave; k < EV.n_targets; k += NEV) eval_one(es[wave], EV, r, k, lane);
   }
   __syncthreads();
-  for (int d0 = KDF0; d0 < n; d0 += KROUND) {
-    const int dmax = min(d0 + KROUND - 1, n - 1);
+  const int Bmax = (n - 1) >> 2;
+  for (int B = KT_BMIN; B <= Bmax; B++) {
     if (wave == 0) {
       int seen = 0;
-      const bool ok = strip_wait(flagA, A.hbase, dmax - KLAG, seen);
+      const bool ok = strip_wait(flagA, A.hbase, 4 * B - 5 - PKE, seen);
       if (lane == 0 && (!ok || seen == A.hbase + STRIP_DONE)) ctl[0] = 1;        // the main workgroup is gone (bad character) or lost
     }
     __syncthreads();
     if (ctl[0]) break;
-    // items (diagonal, 32-cell block, sub-sum), dealt to the waves in order
-    int itbase = 0;
-    for (int dd = 0; dd <= dmax - d0; dd++) {
-      const int d = d0 + dd, ncell = n - d, kfsh = kfar_sub_shift(ncell);
-      const int cnt = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kfsh;      // (DRNA_SKIP: timing builds)
-      for (int it = (wave + NW - itbase % NW) % NW; it < cnt; it += NW) {
-        const int blk = it >> kfsh, sub = it & ((1 << kfsh) - 1), cl = lane & 15, row = lane >> 4;
-        int i = (blk << 5) + 2 * cl + 1;
-        const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
-        i = act0 ? i : 1;
-        double v0, v1;
-        k_far_row<true>(rsX, (int)tab * 8, ld, d, i, sub * 4 + row, 4 << kfsh, v0, v1);
-        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-        if (lane < 16) {
-          if (act0) part[(dd * 4 + sub) * 256 + i] = v0;
-          if (act1) part[(dd * 4 + sub) * 256 + i + 1] = v1;
-        }
+    if (!(DRNA_SKIP & 8))                                                         // (DRNA_SKIP: timing builds)
+      for (int a = wave; a <= Bmax - B; a += NW) {
+        KTile t;
+        k_tile_issue<true>(rsX, (int)tab * 8, ld, n, a, B, lane, t);
+        k_tile_finish<true>(rsX, ld, t, n, lane, [&](int d, int i, double v) { st_agent(&DFAR[d * ld + i], v); });
       }
-      itbase += cnt;
-    }
-    __syncthreads();
-    for (int t = tid; t < KROUND * 256; t += NT) {
-      const int dd = t >> 8, i = t & 255, d = d0 + dd;
-      if (d <= dmax && i >= 1 && i <= n - d) {
-        const double* p = part + dd * 4 * 256 + i;
-        st_agent(&DFAR[d * ld + i], ((p[0] + p[256]) + p[512]) + p[768]);       // the order pf_lds_kernel's finalize uses for partF
-      }
-    }
     drain_vmem();
     __syncthreads();
-    if (tid == 0) st_agent(flagB, A.hbase + dmax);
+    if (tid == 0) st_agent(flagB, A.hbase + (B == Bmax ? n : 4 * B));           // every diagonal below the next round's first cell is complete
   }
 }
 
@@ -407,6 +466,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   if (tid == 0) {
     sm.xc[0] = T.bulge[1] * A.scale[3]; sm.xc[1] = T.interior[5] * T.eninio[1] * A.scale[7];
     sm.xc[2] = A.scale[4]; sm.xc[3] = A.scale[5]; sm.xc[4] = A.scale[6];
+    sm.xc[8] = eTau; sm.xc[9] = eMLc; sm.xc[10] = eMLi; sm.xc[11] = b1; sm.xc[12] = sc2;
   }
   for (int k = tid; k < 32; k += NT) {
     sm.twc[k][0] = k >= 4 && k <= 30 ? T.eninio[k - 4] : 0.0;
@@ -416,7 +476,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   for (int k = tid; k < 32 * RS; k += NT) { sm.qbi[k] = 0.0; sm.info[k] = 0; }
   for (int k = tid; k < 2 * RS; k += NT) { (&sm.qm1row[0][0])[k] = 0.0; (&sm.urow[0][0])[k] = 0.0; }
   for (int k = tid; k < 2 * 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partG[0][0][0])[k] = 0.0;
-  for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) { (&sm.partK[0][0][0])[k] = 0.0; (&sm.partF[0][0][0])[k] = 0.0; }
+  for (int k = tid; k < 2 * 4 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.partK[0][0][0])[k] = 0.0;
   for (int k = tid; k < 2 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accE[0][0])[k] = 0.0;
   for (int k = tid; k < 6 * PfFastSmem<NT>::NSLOT; k += NT) (&sm.accX[0][0][0])[k] = 0.0;
   if (tid == 0) { sm.flag = 0; sm.q5[0] = 1.0; }
@@ -479,7 +539,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     if (d < n) {
       const int cnt = PL[d * ld + ld - 1];
       if (tid < cnt) sm.plist[d & 1][tid] = PL[d * ld + tid];
-      if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; }
+      if (tid == 0) { sm.pcnt[d & 1] = cnt; sm.qhead[0] = 0; sm.qhead[1] = 0; sm.qtile[0] = 0; sm.qtile[1] = 0; }
     }
   }
   __syncthreads();
@@ -516,38 +576,23 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     // sub-blocks (K, from L2), pairs of pairable cells for the 112 bulge / 1xn shapes (E), three groups of
     // fixed small shapes per 64 pairable cells (X).  Every item owns its output slot(s), so the result does
     // not depend on which wave takes it.
-    // K items: per 32-cell block one NEAR item and, where no helper workgroup does that part, kfar_subs FAR items (see k_far_row)
+    // K items: per 32-cell block one item for the NEAR split points (the far ones: run_tiles, or the helper workgroup)
     const int nblk = (ncell + 31) >> 5;
-    const int F = d >= KDF0 ? d - 2 * KLAG + 2 : 0;            // far split points of this diagonal's cells
-    const int kfsh = kfar_sub_shift(ncell);
-    const int nKf = ((DRNA_SKIP & (8 | 512)) || hm || F == 0) ? 0 : nblk << kfsh;      // (512: timing build without the far split points)
-    const int nK = nKf + (((DRNA_SKIP & 8) || d < 2 * TURN + 3) ? 0 : nblk);
+    const int nK = ((DRNA_SKIP & 8) || d < 2 * TURN + 3) ? 0 : nblk;
     const int nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2, nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
     for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
       if (it < nK) {
-        // ---- K: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
+        // ---- K near: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
         // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
-        const bool far = it < nKf;
-        const int blk = far ? it >> kfsh : it - nKf, cl = lane & 15, row = lane >> 4;
+        const int blk = it, cl = lane & 15, row = lane >> 4;
         int i = (blk << 5) + 2 * cl + 1;
         const bool act0 = i <= ncell, act1 = i + 1 <= ncell;
         i = act0 ? i : 1;
         double v0, v1;
-        if (far) {
-          const int sub = it & ((1 << kfsh) - 1);
-          k_far_row<false>(rsQ, (int)tab * 8, ld, d, i, sub * 4 + row, 4 << kfsh, v0, v1);
-          v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-          v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-          if (lane < 16) {
-            if (act0) sm.partF[par][sub][i + slot0] = v0;
-            if (act1) sm.partF[par][sub][i + 1 + slot0] = v1;
-          }
-        } else {
-          k_near_row(rsQ, (int)tab * 8, ld, d, i, row, F, v0, v1);
-          if (act0) sm.partK[par][row][i + slot0] = v0;
-          if (act1) sm.partK[par][row][i + 1 + slot0] = v1;
-        }
+        k_near_row(rsQ, (int)tab * 8, ld, d, i, row, v0, v1);
+        if (act0) sm.partK[par][row][i + slot0] = v0;
+        if (act1) sm.partK[par][row][i + 1 + slot0] = v1;
       } else if (it < nK + nE) {
         // ---- E: four pairable cells per item, one per 16-lane row.  Lane l of a row takes the loop SIZES t = l + 2 and l + 18
         // (2 .. 30): the two bulges (0,t) (t,0) and the two 1xn loops (1,t-1) (t-1,1) of one size have their inner pairs on
@@ -568,7 +613,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         const double rb1 = sm.rbul[fb1], rb4 = sm.rbul[fb4], rb2 = sm.r1n[fb2], rb3 = sm.r1n[fb3];
         const double bul = (a1 * ra1 + a4 * ra4) * wA.x + (b1_ * rb1 + b4_ * rb4) * wB.x;
         const double one = (a2 * ra2 + a3 * ra3) * wA.y + (b2_ * rb2 + b3_ * rb3) * wB.y;
-        double v = bul * ((ij >> 4) > 2 ? eTau : 1.0) + one * sm.mm1n[ij];
+        double v = bul * ((ij >> 4) > 2 ? sm.xc[as_vector(8)] : 1.0) + one * sm.mm1n[ij];
         v = dpp_add_f64<0x111, 0xF>(v);
         v = dpp_add_f64<0x112, 0xF>(v);
         v = dpp_add_f64<0x114, 0xF>(v);
@@ -593,7 +638,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
             w[shp] = dp > TURN ? sm.qbi[off] : 0.0;
             f[shp] = dp > TURN ? sm.info[off] : 0;
           }
-          sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sc2;
+          sum = w[0] * sm.rinv[f[0]] * sm.stack[t * 8 + (f[0] >> 4)] * sm.xc[as_vector(12)];
           sum += (w[1] * sm.rinv[f[1]] * sm.stack[t * 8 + (f[1] >> 4)] + w[2] * sm.rinv[f[2]] * sm.stack[t * 8 + (f[2] >> 4)]) * sm.xc[as_vector(0)];
           sum += w[3] * sm.rinv[f[3]] * sm.int11[(t * 8 + (f[3] >> 4)) * 16 + si1 * 4 + sj1] * sm.xc[as_vector(2)];
         } else if (grp == 1) {
@@ -619,6 +664,26 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
 #ifdef DRNA_STAMPS
       STAMP(it < nK ? 5 : it < nK + nE ? 1 : 2);
 #endif
+    }
+  };
+
+  // Tile products (no helper workgroup: large batches).  During step d the tiles of block distance Bt, whose first cell is due
+  // 4 - ph diagonals from now, a quarter of them per step (neighbours in one step: they share cache lines); operands on
+  // diagonals <= 4 Bt - 5 - PKE <= d - 3, sums stored (DFAR) a step before the finalize waves ask for them.  A queue of its own
+  // that only the sweep waves serve, first thing after their tower step: in the finalize waves' loop the tile code costs spilled
+  // registers on their critical path (0.50 instead of 0.46 ms at R = 64).  (Measured and dropped: the operands requested as the
+  // last thing of the step before and left in flight across the barrier, so that a tile costs its wave the matrix instructions
+  // and not an L2 round trip -- 4 to 24 operand registers carried over the loop's back edge are 6 to 77 spilled ones:
+  // 0.56 / 0.61 / 0.63 / 0.65 ms for 0 / 1 / 2 / 4 products carried, against 0.54.)
+  auto run_tiles = [&](const int d) {
+    const int Bmax = (n - 1) >> 2, Bt = ((d + 3) >> 2) + 1, ph = (d + 3) & 3;
+    if ((DRNA_SKIP & (8 | 512)) || hm || Bt < KT_BMIN || Bt > Bmax) return;         // (512: timing build without the far split points)
+    const int cnt = Bmax - Bt + 1, per = (cnt + 3) >> 2, a0 = ph * per;
+    const int nT = __builtin_amdgcn_readfirstlane(max(0, min(cnt, a0 + per) - a0));
+    for (int it = queue_pop(&sm.qtile[d & 1], lane); it < nT; it = queue_pop(&sm.qtile[d & 1], lane)) {
+      KTile t;
+      k_tile_issue<false>(rsQ, (int)tab * 8, ld, n, a0 + it, Bt, lane, t);
+      k_tile_finish<false>(rsQ, ld, t, n, lane, [&](int dd, int ii, double v) { DFAR[dd * ld + ii] = v; });
     }
   };
 
@@ -650,22 +715,23 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       }
       int f_req = 0;
       double d_req = 0.0;
+      dfar_cur = dfar_next;
       if (hm) {
         // diagonal k-2 was finalized in step k-1 and every store of it drained by that step's barrier: publish it
         if (tid == 0 && k - 2 > TURN) st_agent(flagA, A.hbase + (k - 2));
-        dfar_cur = dfar_next;
         // The helper's flag and the far sums of the next diagonal are REQUESTED here and taken over at the end of the step
         // (after the items): assigning the loop-carried variables here would make the compiler wait for the loads at once.
         f_req = ld_agent(flagB);
-        if (k >= KDF0 && k < n) {
-          // the flag value of the previous step decides (the helper runs rounds ahead, an old value will do)
-          if (!helper_lost && !flag_ge(fb_last, A.hbase + k)) {       // rare: the helper is not a step ahead -- wait here
-            int seen = 0;
-            if (!strip_wait(flagB, A.hbase, k, seen)) { sm.flag = 2; helper_lost = true; }     // one expired wait per wave, then no more
-          }
-          const int ic = tid + 1 - (k >> 1) - off0;
-          d_req = (ic >= 1 && ic <= n - k) ? ld_agent(&DFAR[k * ld + ic]) : 0.0;
+        if (k >= KT_D0 && k < n && !helper_lost && !flag_ge(fb_last, A.hbase + k)) {
+          // the flag value of the previous step decides (the helper is ahead as a rule; an old value will do); else wait here
+          int seen = 0;
+          if (!strip_wait(flagB, A.hbase, k, seen)) { sm.flag = 2; helper_lost = true; }     // one expired wait per wave, then no more
         }
+      }
+      if (k >= KT_D0 && k < n) {
+        // far sums of diagonal k: the helper's (sc1) or this workgroup's own tile items', stored in a step before this one
+        const int ic = tid + 1 - (k >> 1) - off0;
+        if (ic >= 1 && ic <= n - k && kt_has_far(ic, k)) d_req = hm ? ld_agent(&DFAR[k * ld + ic]) : DFAR[k * ld + ic];
       }
       TLMARK2(0, k);
       if (d > TURN) {
@@ -679,17 +745,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
                     sj1 = sm.S[j - 1], sim = sm.S[i - 1], sjp = sm.S[j + 1];
           const double aG = d >= 10 ? sm.partG[par][0][tid] + sm.partG[par][1][tid] : 0.0;
           const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
-          double aKf = 0.0;
-          if (hm) aKf = dfar_cur;
-          else if (d >= KDF0) {                    // ((p0 + p1) + p2) + p3 with the sub-sums that exist (the others count as zero)
-            const int kfsh = kfar_sub_shift(ncell);
-            aKf = sm.partF[par][0][tid];
-            if (kfsh >= 1) aKf += sm.partF[par][1][tid];
-            if (kfsh >= 2) aKf = (aKf + sm.partF[par][2][tid]) + sm.partF[par][3][tid];
-          }
-          const double aK = aKn + aKf;
+          const double aK = aKn + dfar_cur;        // (zero for a cell without far split points)
           const int t = pair_type(si, sj);
-          const double tau = t > 2 ? eTau : 1.0;
+          const double cTau = sm.xc[as_vector(8)], cMLc = sm.xc[as_vector(9)], cMLi = sm.xc[as_vector(10)], cb1 = sm.xc[as_vector(11)],
+                       csc2 = sm.xc[as_vector(12)];
+          const double tau = t > 2 ? cTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
           const double aE = sm.accE[par][tid], aX = (sm.accX[par][0][tid] + sm.accX[par][1][tid]) + sm.accX[par][2][tid];
@@ -717,15 +777,15 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
               hp = sm.hpw[u] * wH;
             }
             qb = hp + aE + aX + aG * wI;
-            qb += dprev * eMLc * eMLi * tau * wMc * sc2;
+            qb += dprev * cMLc * cMLi * tau * wMc * csc2;
           }
           sm.qbi[(d & 31) * RS + i] = qb * wInfo;
           sm.info[(d & 31) * RS + i] = (unsigned char)info;
           const double me = (i > 1 && j < n) ? wExt : i > 1 ? w5 : j < n ? w3 : 1.0;
           const double mm = (i > 1 && j < n) ? wMs : i > 1 ? w5 : j < n ? w3 : 1.0;
-          const double ext = t ? qb * tau * me : 0.0, stem = t ? qb * eMLi * tau * mm : 0.0;
-          const double m1 = m1p * b1 + stem;
-          const double U = b1 * (m1q + up);
+          const double ext = t ? qb * tau * me : 0.0, stem = t ? qb * cMLi * tau * mm : 0.0;
+          const double m1 = m1p * cb1 + stem;
+          const double U = cb1 * (m1q + up);
           sm.qm1row[par][i] = m1;
           sm.urow[par][i] = U;
           sm.dring[(d & 3) * RS + i] = aK;
@@ -742,7 +802,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         int* dst = sm.plist[(k + 1) & 1];
         dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
         if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = pl3;
-        if (lane == 0) { sm.pcnt[(k + 1) & 1] = pl_cnt; sm.qhead[(k + 1) & 1] = 0; }
+        if (lane == 0) { sm.pcnt[(k + 1) & 1] = pl_cnt; sm.qhead[(k + 1) & 1] = 0; sm.qtile[(k + 1) & 1] = 0; }
       }
       if (job_q5) {
         // q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j): four strided terms per lane, fixed-order wave sum
@@ -759,7 +819,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       TLMARK(1, k);
       if (!(DRNA_SKIP & 128) && k < n) run_items(k);          // help the sweep of diagonal k
       TLMARK(2, k);
-      if (hm) { dfar_next = d_req; fb_last = __builtin_amdgcn_readfirstlane(f_req); }
+      dfar_next = d_req;
+      if (hm) fb_last = __builtin_amdgcn_readfirstlane(f_req);
       __syncthreads();
       STAMP(3);
 #ifdef DRNA_STAMPS
@@ -777,6 +838,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int lo = sh + off0, hi = ncell + sh + off0 - 1;
+
         // ---- T: tower step
         if (!(DRNA_SKIP & 1) && ((my_pm >> par) & 1) && d >= 10) {
           const int blo = T0 + my_tb * WAVE;                        // the block's slots blo .. blo + 63; the diagonal's cells lo .. hi
@@ -794,6 +856,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         }
         STAMP(0);
         TLMARK(1, k);
+        run_tiles(d);
+        TLMARK3(k);
         run_items(d);
         STAMP(6);
         TLMARK(2, k);

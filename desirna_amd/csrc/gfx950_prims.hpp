@@ -17,16 +17,8 @@ __device__ __forceinline__ long long wall_clock_100mhz() { return (long long)wal
 // wait until at most N of the wave's vector-memory operations are outstanding (they retire in issue order)
 template <int N>
 __device__ __forceinline__ void stores_in_flight() {
-  static_assert(N >= 0 && N <= 9, "stores_in_flight: counts 0..9");
-  if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "stores_in_flight: the counter has six bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // A wait for another workgroup is bounded by TIME: HIP promises no dispatch order, so a partner may never have been scheduled,
@@ -61,6 +53,11 @@ __device__ __forceinline__ double fma3_f64(double a, double b, double c) {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products (block = (l >> 2) & 3): A[i][k] in lane i + 4 block + 16 k,
+// B[k][j] in lane j + 4 block + 16 k, D[i][j] in lane j + 4 block + 16 i (found by experiment: tools/probe/mfma4x4_probe.hip)
+__device__ __forceinline__ double mfma_f64_4x4x4_4b(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
 }  // namespace drna

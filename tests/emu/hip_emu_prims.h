@@ -37,5 +37,14 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
   }
   return c;
 }
+// v_mfma_f64_4x4x4_4b_f64 (lane layout: gfx950_prims.hpp)
+__device__ __forceinline__ double mfma_f64_4x4x4_4b(double a, double b, double c) {
+  const int lane = threadIdx.x & 63, j = lane & 3, blk4 = lane & 12, i = lane >> 4;
+  for (int k = 0; k < 4; k++) {
+    const double ak = emu_exchange(a, i + blk4 + 16 * k), bk = emu_exchange(b, j + blk4 + 16 * k);
+    c = std::fma(ak, bk, c);
+  }
+  return c;
+}
 
 }  // namespace drna

@@ -7,26 +7,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from desirna_amd import engine as E
 import bench
-tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = 64
+tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = int(os.environ.get("TL_R", "64"))      # TL_R=128: no helper workgroups
 rng = np.random.default_rng(20260101)
 seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
 lib = os.path.join(ROOT, "build", "var", "lib_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "tl"))
 MFE = len(sys.argv) > 2 and sys.argv[2] == "mfe"          # the MFE kernel's marks (table 2 of its workspace) instead of the PF kernel's
 eng = E.Engine(max_R=R, max_L=L, lib=lib)
 eng.set_targets([tg])
+for kv in os.environ.get("TL_OPTS", "").split():          # e.g. TL_OPTS="pf_helper=0 dual=0"
+    k, v = kv.split("="); eng.set_option(k, int(v))
 for _ in range(3):
     eng.score_batch(seqs, E.NEED_MFE | E.NEED_PF)
 print(eng.last_timing())
 ld = L + 2; tab = ld * ld
 eng._L.drna_debug_read_pf_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
-buf = np.zeros(16 * 3 * 256 + 4 * 3 * 256, dtype=np.float64)
+buf = np.zeros(16 * 3 * 256 + 4 * 3 * 256 + 16 * 256, dtype=np.float64)
 if MFE:
     eng._L.drna_debug_read_mfe_ws.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
     eng._L.drna_debug_read_mfe_ws(eng._h, 2 * tab, 16 * 3 * 256 * 2, buf.ctypes.data)
 else:
     eng._L.drna_debug_read_pf_ws(eng._h, 4 * tab + tab // 2, buf.size, buf.ctypes.data)
 t = buf.view(np.int64)[:16 * 3 * 256].reshape(16, 3, 256).astype(np.float64) / 100.0      # microseconds
-t2 = buf.view(np.int64)[16 * 3 * 256:].reshape(4, 3, 256).astype(np.float64) / 100.0
+t2 = buf.view(np.int64)[16 * 3 * 256:16 * 3 * 256 + 4 * 3 * 256].reshape(4, 3, 256).astype(np.float64) / 100.0
+t3 = buf.view(np.int64)[60 * 256:76 * 256].reshape(16, 256).astype(np.float64) / 100.0       # PF sweep waves: tile products done (zero without tiles)
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     ks = np.arange(lo, hi)
     t0 = t[:, 0, ks].min(axis=0)                      # first wave out of the barrier
@@ -37,4 +40,6 @@ for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
         extra = ""
         if w < 4 and not MFE:
             extra = "   [requests issued +%.2f  cells finalized +%.2f]" % ((t2[w, 0, ks] - t0).mean(), (t2[w, 1, ks] - t0).mean())
+        if w >= 4 and not MFE and t3[w, ks].max() > 0:
+            extra = "   [tile products: %.2f us]" % (t3[w, ks] - t[w, 1, ks]).mean()
         print("   wave %2d: out of barrier +%.2f  own job done +%.2f  items done +%.2f%s" % (w, a, b, c, extra))
