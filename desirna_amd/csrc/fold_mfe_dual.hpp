@@ -46,6 +46,8 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
   const int n = A.L, tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int INF = INF_DEV, TermAU = T.TermAU;
+  int32_t* const PL = A.ws + (long long)r * A.ws_stride + 3LL * A.ld * A.ld;      // the main role's list tables (mfe_lds_body)
+  int32_t* const PLX = A.ws + (long long)r * A.ws_stride + 1LL * A.ld * A.ld;
   const int32_t* const xw = reinterpret_cast<const int32_t*>(lk.xa);
   const int32_t* const xf = xw + (MFE_FAST_NMAX + 2) * XP;
   int32_t* const xk = reinterpret_cast<int32_t*>(lk.xb);
@@ -113,12 +115,17 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     if (sm.fail) break;
     for (int k = tid; k <= n + 1; k += NT) sm.Sp[k] = (unsigned char)ld_agent(lk.xs + k);
     __syncthreads();
-    if (wave == 0 && TURN + 1 < n) prepare(TURN + 1);
+    // the main role's pairable lists from diagonal PL_D1 on (mfe_pl_row): it reads the first of them after it has seen a flag of this
+    // round, which is raised behind the barrier below
+    for (int d = PL_D1 + wave; d < n; d += NT / WAVE) mfe_pl_row<true>(sm, T, PL, PLX, A.ld, n, d, lane, TermAU);
+    drain_vmem();
+    __syncthreads();
+    if (wave == 0 && DUAL_D0 < n) prepare(DUAL_D0);
     __syncthreads();
 
     int fa = 0;
     if (wave == 0) fa = ld_agent(lk.flagA);
-    for (int D = TURN + 1; D <= n + 1; D++) {        // steps D = n, n+1 only ship the last diagonal and raise its flag
+    for (int D = DUAL_D0; D <= n + 1; D++) {         // steps D = n, n+1 only ship the last diagonal and raise its flag
       const int par = D & 1, ncell = n - D;
       if (wave == 0) {
         // ---- inbound: rows of diagonal D+1-DLAG (needed from diagonal D+1 on); the flag was read at the end of the
@@ -150,9 +157,9 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
         // ---- outbound: the flag of diagonal D-2 (its minima were stored during the previous step: they have landed by
         // now, so the wait is short), then the minima of diagonal D-1 (reset for diagonal D+1)
         drain_vmem();
-        if (lane == 0 && D - 2 > TURN) st_agent(lk.flagB, base + D - 2);
+        if (lane == 0 && D - 2 >= DUAL_D0) st_agent(lk.flagB, base + D - 2);
         const int ds = D - 1;
-        if (ds > TURN && ds < n) {
+        if (ds >= DUAL_D0 && ds < n) {
           const int ps = ds & 1;
           for (int i = lane + 1; i <= n - ds; i += WAVE) {
             st_agent(xk + ds * XP + i, (int32_t)sm.accK[ps][i]);

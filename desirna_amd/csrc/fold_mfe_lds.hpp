@@ -457,6 +457,52 @@ __device__ __forceinline__ void mfe_e_item_rows(SM& sm, int e, int d, int par, i
 //       K  multiloop splits tt = 4 + aw (mod NA) for all cells, lane = cell.
 // Uniform bookkeeping comes from LDS tables, not from scalar arithmetic: the scalar unit is shared by
 // the 16 waves and was the bottleneck of earlier versions of this kernel.
+// ---- compacted list of the pairable cells of diagonal d (one wave): list word i | pair info << 8 | e(2,2) << 15 and the staged
+// (1,2) / (2,1) loop energies.  These three small loops depend on the sequence alone, so their table energies (L2) are fetched
+// here, once per fill, instead of on the per-diagonal critical path (inner TermAU taken out: it is folded into the ring word).
+// A row costs a wave ~0.8 us per 64 cells (the table loads' round trip): 20 us of prologue for 196 rows on sixteen waves.  In
+// the two-workgroup kernel the main role builds the rows below PL_D1 only and its HELPER, which has nothing to do until the main
+// role's tenth diagonal, the rest (AGENT: stored write-through, read sc1): the main role's prologue is 16 us shorter.
+#ifndef DRNA_PL_D1
+#define DRNA_PL_D1 28
+#endif
+constexpr int PL_D1 = DRNA_PL_D1;
+constexpr int DUAL_D0 = 2 * TURN + 3;      // first diagonal the helper contributes to (a far shape's inner pair is >= 5 diagonals back)
+static_assert(PL_D1 >= DUAL_D0 + 3, "the main role reads a helper-built row only after it has seen the helper's first flag");
+template <bool AGENT, class SM>
+__device__ __forceinline__ void mfe_pl_row(const SM& sm, const MfeTables& T, int32_t* PL, int32_t* PLX, int ld, int n, int d, int lane,
+                                           int TermAU) {
+  int base = 0;
+  for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+    const int i = i0 + lane;
+    int t = 0;
+    if (i <= n - d) t = pair_type(sm.Sp[i], sm.Sp[i + d]);
+    const unsigned long long m = __ballot(t != 0);
+    if (t) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      const int j = i + d, si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
+      const bool va = d - 5 > TURN, vc = d - 6 > TURN;
+      const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
+                tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
+      const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
+      const int s_ip2 = sm.S[i + 2], s_jm2 = sm.S[j - 2];
+      const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
+      const int eb = T.int21[tb ? (rb * 8 + t) * 64 + sj1 * 16 + si1 * 4 + s_ip2 : 0];
+      const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
+      const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
+                cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
+      const int32_t w = (i | ((t * 16 + si1 * 4 + sj1) << 8)) | (cc << 15), x = (a & 0xffff) | (b << 16);
+      if (AGENT) { st_agent(&PL[d * ld + pos], w); st_agent(&PLX[d * ld + pos], x); }
+      else { PL[d * ld + pos] = w; PLX[d * ld + pos] = x; }
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) {                              // count kept in the last word of the row
+    if (AGENT) st_agent(&PL[d * ld + ld - 1], (int32_t)base);
+    else PL[d * ld + ld - 1] = base;
+  }
+}
+
 template <int NT, bool DUAL = false>
 __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs& A, int32_t* __restrict__ Wc, int32_t* __restrict__ EXT,
                              int32_t* __restrict__ PL, int32_t* __restrict__ PLX, DualLink lk = DualLink{}) {
@@ -484,6 +530,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   // +1.33 for the cell finalize alone)
   const int w_et = NB > 3 ? 2 : w_tab;
 
+  if (DUAL) {
+    // round prologue for the helper workgroup, first thing: the pairing codes of this round (masked positions = 4), then the
+    // flag -- the helper builds the pairable lists of the diagonals from PL_D1 on while this workgroup fills its tables
+    int32_t* xs = lk.xs;
+    for (int k = tid; k <= n + 1; k += NT) st_agent(xs + k, (int32_t)sm.Sp[k]);
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0) { st_agent(lk.flagA, lk.base + TURN); sm.sync_fail = 0; }
+  }
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
   for (int k = tid; k < 32 * RS; k += NT) { sm.wring[k] = INF * 256; sm.ciring[k] = INF; }   // idle tower entries read row 0
@@ -531,45 +586,9 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     sm.xtab[SM::XT_MM23 + k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
   }
   for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
-  for (int d = TURN + 1 + wave; d < n; d += NW) {
-    int base = 0;
-    for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
-      const int i = i0 + lane;
-      int t = 0;
-      if (i <= n - d) t = pair_type(sm.Sp[i], sm.Sp[i + d]);
-      const unsigned long long m = __ballot(t != 0);
-      if (t) {
-        // list word i | pair info << 8 | e(2,2) << 15 and the staged (1,2) / (2,1) loop energies: these three small loops
-        // depend on the sequence alone, so their table energies (L2) are fetched here, once per fill, instead of on the
-        // per-diagonal critical path (inner TermAU taken out: it is folded into the ring word)
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        const int j = i + d, si1 = sm.S[i + 1], sj1 = sm.S[j - 1];
-        const bool va = d - 5 > TURN, vc = d - 6 > TURN;
-        const int ta = va ? pair_type(sm.Sp[i + 2], sm.Sp[j - 3]) : 0, tb = va ? pair_type(sm.Sp[i + 3], sm.Sp[j - 2]) : 0,
-                  tc = vc ? pair_type(sm.Sp[i + 3], sm.Sp[j - 3]) : 0;
-        const int ra = rtype_of(ta), rb = rtype_of(tb), rc = rtype_of(tc);
-        const int s_ip2 = sm.S[i + 2], s_jm2 = sm.S[j - 2];
-        const int ea = T.int21[ta ? (t * 8 + ra) * 64 + si1 * 16 + s_jm2 * 4 + sj1 : 0];
-        const int eb = T.int21[tb ? (rb * 8 + t) * 64 + sj1 * 16 + si1 * 4 + s_ip2 : 0];
-        const int ec = T.int22[tc ? (t * 8 + rc) * 256 + si1 * 64 + s_ip2 * 16 + s_jm2 * 4 + sj1 : 0];
-        const int a = ta ? ea - (ra > 2 ? TermAU : 0) : 0, b = tb ? eb - (rb > 2 ? TermAU : 0) : 0,
-                  cc = tc ? ec - (rc > 2 ? TermAU : 0) : 0;
-        PL[d * ld + pos] = (i | ((t * 16 + si1 * 4 + sj1) << 8)) | (cc << 15);
-        PLX[d * ld + pos] = (a & 0xffff) | (b << 16);
-      }
-      base += __popcll(m);
-    }
-    if (lane == 0) PL[d * ld + ld - 1] = base;     // count kept in the last word of the row
-  }
+  // (two-workgroup kernel: the rows from PL_D1 on are the helper's, see mfe_pl_row)
+  for (int d = TURN + 1 + wave; d < (DUAL ? min(n, PL_D1) : n); d += NW) mfe_pl_row<DUAL>(sm, T, PL, PLX, ld, n, d, lane, TermAU);
   __syncthreads();
-  if (DUAL) {
-    // round prologue for the helper workgroup: the pairing codes of this round (masked positions = 4), then the flag
-    int32_t* xs = lk.xs;
-    for (int k = tid; k <= n + 1; k += NT) st_agent(xs + k, (int32_t)sm.Sp[k]);
-    drain_vmem();
-    __syncthreads();
-    if (tid == 0) { st_agent(lk.flagA, lk.base + TURN); sm.sync_fail = 0; }
-  }
   // tables and pairable list of the first diagonal
   if (aw < 0) {
     const int d = TURN + 1;
@@ -607,11 +626,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     auto pl_request = [&](const int dn) {
       const int32_t* row = PL + dn * ld;
       const int32_t* rowx = PLX + dn * ld;
-      pw_cnt = row[ld - 1];
+      pw_cnt = DUAL ? ld_agent(row + ld - 1) : row[ld - 1];       // (two-workgroup kernel: the helper may have written the row)
       const int nch = (n - dn + WAVE - 1) >> 6;                 // chunks the diagonal's cells can fill (uniform, known without the count)
 #pragma unroll
       for (int c = 0; c < 4; c++)
-        if (c < nch) { pw[c] = row[min(lane + c * WAVE, ld - 1)]; px[c] = rowx[min(lane + c * WAVE, ld - 1)]; }
+        if (c < nch) {
+          const int o = min(lane + c * WAVE, ld - 1);
+          pw[c] = DUAL ? ld_agent(row + o) : row[o];
+          px[c] = DUAL ? ld_agent(rowx + o) : rowx[o];
+        }
     };
     if (wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
@@ -626,7 +649,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       bool rq_have = false, rq_on = false;
       if (DUAL && d > TURN) {
         const int i2 = tid + 1 - ((d + 1) >> 1) - off0;
-        rq_have = d + 1 < n && flag_ge(fb_s, lk.base + d + 1);
+        rq_have = d + 1 < n && d + 1 >= DUAL_D0 && flag_ge(fb_s, lk.base + d + 1);
         rq_on = rq_have && i2 >= 1 && i2 <= n - d - 1;
         rqK = ld_agent(rq_on ? xk + (d + 1) * XP + i2 : lk.flagB);
         rqI = ld_agent(rq_on ? xi + (d + 1) * XP + i2 : lk.flagB);
@@ -666,7 +689,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         const int i = tid + 1 - sh - off0;
         const int dv = as_vector(d), dm1v = as_vector(d - 1);   // uniform LDS indices kept in VGPRs (outside divergent code)
         int bK = pfK, bI = pfI;
-        if (DUAL) {
+        if (DUAL && d >= DUAL_D0) {                              // (before that diagonal the helper has nothing to add)
           if (!have) {                                           // not fetched ahead: wait for the helper here
             if (!sm.sync_fail && !wait_flag_wave(lk.flagB, lk.base + d)) sm.sync_fail = 1;
             const bool on = i >= 1 && i <= ncell;

@@ -362,6 +362,32 @@ __device__ __forceinline__ void k_tile_finish(RS rs, int ld, const KTile& t, int
 #endif
 #endif
 
+// ---- compacted list of the pairable cells of diagonal d (one wave): i | (pair type, inner neighbours) << 8, the count in the
+// row's last word.  With a helper workgroup the main workgroup builds the rows below PFL_D1 only; the helper, idle until the first
+// far split point, builds the rest while the main workgroup is on its first diagonals (AGENT: stored write-through, read sc1)
+// and says so with its first flag: 7 us less prologue for the main workgroup.
+#ifndef DRNA_PFL_D1
+#define DRNA_PFL_D1 24
+#endif
+constexpr int PFL_D1 = DRNA_PFL_D1;
+template <bool AGENT, class SM>
+__device__ __forceinline__ void pf_pl_row(const SM& sm, int32_t* PL, int ld, int n, int d, int lane) {
+  int cntb = 0;
+  for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
+    const int i = i0 + lane;
+    int t = 0;
+    if (i <= n - d) t = pair_type(sm.S[i], sm.S[i + d]);
+    const unsigned long long m = __ballot(t != 0);
+    if (t) {
+      const int pos = cntb + __popcll(m & ((1ull << lane) - 1ull));
+      const int32_t w = i | ((t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1]) << 8);
+      if (AGENT) st_agent(&PL[d * ld + pos], w); else PL[d * ld + pos] = w;
+    }
+    cntb += __popcll(m);
+  }
+  if (lane == 0) { if (AGENT) st_agent(&PL[d * ld + ld - 1], (int32_t)cntb); else PL[d * ld + ld - 1] = cntb; }
+}
+
 // ---- helper workgroup of pf_lds_kernel (small batches: idle CUs): the FAR multiloop split points of every tile, from the
 // rows the main workgroup publishes.  Hand-over as the CDNA4 guide prescribes (and as fold_mfe_dual.hpp does it): payload by
 // sc1 stores into tables of its own (XQM, XQM1: tables 0 and 1 of the sequence's workspace, which this kernel does not use
@@ -392,7 +418,19 @@ __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& 
     if (wave < NEV)
       for (int k = wave; k < EV.n_targets; k += NEV) eval_one(es[wave], EV, r, k, lane);
   }
+  // the main workgroup's pairable lists from diagonal PFL_D1 on (pf_pl_row), announced by the first flag: far sums complete below
+  // the first diagonal that has any
+  {
+    const char* seq = A.seqs + (A.rg.off ? (long long)A.rg.off[r] : (long long)r * n);
+    for (int k = tid; k < n; k += NT) { const int c = enc_nt(seq[k]); sm.S[k + 1] = (unsigned char)(c < 0 ? 0 : c); }
+    if (tid == 0) { sm.S[0] = 0; sm.S[n + 1] = 0; }
+    __syncthreads();
+    int32_t* PL = reinterpret_cast<int32_t*>(base + 4 * tab);
+    for (int d = PFL_D1 + wave; d < n; d += NW) pf_pl_row<true>(sm, PL, ld, n, d, lane);
+    drain_vmem();
+  }
   __syncthreads();
+  if (tid == 0) st_agent(flagB, A.hbase + KT_D0 - 1);
   const int Bmax = (n - 1) >> 2;
   for (int B = KT_BMIN; B <= Bmax; B++) {
     if (wave == 0) {
@@ -442,6 +480,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   int32_t* PL = reinterpret_cast<int32_t*>(base + 4 * tab);   // compacted pairable-cell lists, one row per diagonal
   double* QEXT = base + 6 * tab;
 
+#ifdef DRNA_TL
+  long long* tl = reinterpret_cast<long long*>(base + 4 * tab + tab / 2);
+  const bool tl_on = r == 0;
+  TLMARK(0, 0);                       // kernel entry (steps start at TURN + 1: slots 0 .. 3 are free); 1: prologue done; 2, 3: epilogue
+#endif
   const double eTau = T.TermAU, eMLc = T.MLclosing, eMLi = T.MLintern;
   const double b1 = A.eMLb[1], sc1 = A.scale[1], sc2 = A.scale[2];
 
@@ -497,22 +540,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   if (wave == 0) {                                   // q5[j] = scale^j while no pair fits (j <= TURN + 1)
     for (int j = 1; j <= n && j <= TURN + 1; j++) sm.q5[j] = sm.q5[j - 1] * sc1;
   }
-  // compacted list of pairable cells of every diagonal (HBM/L2)
-  for (int d = TURN + 1 + wave; d < n; d += NW) {
-    int cntb = 0;
-    for (int i0 = 1; i0 <= n - d; i0 += WAVE) {
-      const int i = i0 + lane;
-      int t = 0;
-      if (i <= n - d) t = pair_type(sm.S[i], sm.S[i + d]);
-      const unsigned long long m = __ballot(t != 0);
-      if (t) {
-        const int pos = cntb + __popcll(m & ((1ull << lane) - 1ull));
-        PL[d * ld + pos] = i | ((t * 16 + sm.S[i + 1] * 4 + sm.S[i + d - 1]) << 8);
-      }
-      cntb += __popcll(m);
-    }
-    if (lane == 0) PL[d * ld + ld - 1] = cntb;
-  }
+  // compacted list of pairable cells of every diagonal (HBM/L2); with a helper workgroup the rows from PFL_D1 on are the helper's
+  for (int d = TURN + 1 + wave; d < (hm ? min(n, PFL_D1) : n); d += NW) pf_pl_row<false>(sm, PL, ld, n, d, lane);
   __syncthreads();
 
   // tower blocks, centred on the sequence
@@ -544,10 +573,6 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   }
   __syncthreads();
 
-#ifdef DRNA_TL
-  long long* tl = reinterpret_cast<long long*>(base + 4 * tab + tab / 2);
-  const bool tl_on = r == 0;
-#endif
 #ifdef DRNA_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long st_last = clock64();
@@ -564,7 +589,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   const int* flagB = hm ? A.hflags + (long long)r * 64 + 32 : nullptr;
   double dfar_cur = 0.0, dfar_next = 0.0;
   int fb_last = 0;                  // (a zero flag never compares as published: epochs start at 1)
-  bool helper_lost = false;
+  bool helper_lost = false, pl_seen = false;
   // Floating work items of diagonal d, taken from a work queue (LDS counter).  The sweep waves run this after their tower
   // step; the finalize waves, which are done with diagonal d-1 long before the sweep of d ends, join in: every item owns
   // its output slots and reads nothing the current step writes, so the result does not depend on who takes it.
@@ -701,8 +726,19 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       int pl_cnt = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
       if (job_pl) {
         const int32_t* row = PL + (k + 1) * ld;
-        pl_cnt = row[ld - 1];
-        pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
+        if (hm && k + 1 >= PFL_D1) {                                  // the helper's rows: after its first flag, sc1
+          if (!pl_seen) {
+            int seen = 0;
+            if (!helper_lost && !flag_ge(fb_last, A.hbase + KT_D0 - 1) && !strip_wait(flagB, A.hbase, KT_D0 - 1, seen)) { sm.flag = 2; helper_lost = true; }
+            pl_seen = true;
+          }
+          pl_cnt = ld_agent(row + ld - 1);
+          pl0 = ld_agent(row + lane); pl1 = ld_agent(row + lane + WAVE); pl2 = ld_agent(row + lane + 2 * WAVE);
+          pl3 = ld_agent(row + min(lane + 3 * WAVE, ld - 1));
+        } else {
+          pl_cnt = row[ld - 1];
+          pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
+        }
       }
       double qx0 = 0.0, qx1 = 0.0, qx2 = 0.0, qx3 = 0.0;
       if (job_q5) {
@@ -875,6 +911,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
 #endif
+  TLMARK(0, 2);
   // the remaining exterior columns, then Z
   if (wave == 0) {
     for (int j = max(TURN + 2, n - 2); j <= n; j++) pf_q5_column<NT>(sm, QEXT, ld, j, lane, sc1);
@@ -889,6 +926,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       }
       if (hm) st_agent(flagA, A.hbase + STRIP_DONE);
     }
+    TLMARK(0, 3);
   }
 }
 

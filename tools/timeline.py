@@ -11,6 +11,7 @@ tg = bench.load_target("eteV1_69.txt"); L = len(tg); R = int(os.environ.get("TL_
 rng = np.random.default_rng(20260101)
 seqs = ["".join(rng.choice(list("ACGU"), L)) for _ in range(R)]
 lib = os.path.join(ROOT, "build", "var", "lib_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "tl"))
+TURN1 = 4
 MFE = len(sys.argv) > 2 and sys.argv[2] == "mfe"          # the MFE kernel's marks (table 2 of its workspace) instead of the PF kernel's
 eng = E.Engine(max_R=R, max_L=L, lib=lib)
 eng.set_targets([tg])
@@ -30,6 +31,9 @@ else:
 t = buf.view(np.int64)[:16 * 3 * 256].reshape(16, 3, 256).astype(np.float64) / 100.0      # microseconds
 t2 = buf.view(np.int64)[16 * 3 * 256:16 * 3 * 256 + 4 * 3 * 256].reshape(4, 3, 256).astype(np.float64) / 100.0
 t3 = buf.view(np.int64)[60 * 256:76 * 256].reshape(16, 256).astype(np.float64) / 100.0       # PF sweep waves: tile products done (zero without tiles)
+if not MFE and t[0, 0, 0] > 0:
+    print("PF main workgroup: kernel entry -> first step %.2f us, steps %.2f us, last barrier -> Z stored %.2f us" %
+          (t[0, 0, TURN1] - t[0, 0, 0], t[0, 0, 2] - t[0, 0, TURN1], t[0, 0, 3] - t[0, 0, 2]))
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     ks = np.arange(lo, hi)
     t0 = t[:, 0, ks].min(axis=0)                      # first wave out of the barrier
