@@ -714,6 +714,25 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
 
   if (aw < 0) {
     // ================= finalize waves: diagonal d = k-1 at step k
+    // the staged list row travels in registers from the step that requests it to the next one (wave w_pl)
+    int pl_cnt = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
+    auto pl_request = [&](const int dn) {
+      const int32_t* row = PL + dn * ld;
+      if (hm && dn >= PFL_D1) {                                       // the helper's rows: after its first flag, sc1
+        if (!pl_seen) {
+          int seen = 0;
+          if (!helper_lost && !flag_ge(fb_last, A.hbase + KT_D0 - 1) && !strip_wait(flagB, A.hbase, KT_D0 - 1, seen)) { sm.flag = 2; helper_lost = true; }
+          pl_seen = true;
+        }
+        pl_cnt = ld_agent(row + ld - 1);
+        pl0 = ld_agent(row + lane); pl1 = ld_agent(row + lane + WAVE); pl2 = ld_agent(row + lane + 2 * WAVE);
+        pl3 = ld_agent(row + min(lane + 3 * WAVE, ld - 1));
+      } else {
+        pl_cnt = row[ld - 1];
+        pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
+      }
+    };
+    if (!(DRNA_SKIP & 32) && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       TLMARK(0, k);
@@ -721,25 +740,20 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       // column j = k-3 (its cells were stored in step <= k-3 and drained by that step's barrier).  Their global loads are
       // REQUESTED here, before this step's stores, and consumed after the cell finalize: vector-memory operations retire in
       // order, so a wait for them does not wait for the (write-through) stores behind them.
-      const bool job_pl = !(DRNA_SKIP & 32) && k + 1 < n && wave == w_pl;
-      const bool job_q5 = !(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2;
-      int pl_cnt = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
-      if (job_pl) {
-        const int32_t* row = PL + (k + 1) * ld;
-        if (hm && k + 1 >= PFL_D1) {                                  // the helper's rows: after its first flag, sc1
-          if (!pl_seen) {
-            int seen = 0;
-            if (!helper_lost && !flag_ge(fb_last, A.hbase + KT_D0 - 1) && !strip_wait(flagB, A.hbase, KT_D0 - 1, seen)) { sm.flag = 2; helper_lost = true; }
-            pl_seen = true;
-          }
-          pl_cnt = ld_agent(row + ld - 1);
-          pl0 = ld_agent(row + lane); pl1 = ld_agent(row + lane + WAVE); pl2 = ld_agent(row + lane + 2 * WAVE);
-          pl3 = ld_agent(row + min(lane + 3 * WAVE, ld - 1));
-        } else {
-          pl_cnt = row[ld - 1];
-          pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
+      // The list row of diagonal k+1 was requested a whole step ago (with a helper workgroup the late rows are the helper's: they
+      // come from beyond this XCD's L2, ~2 us, and with the request at the top of the SAME step the staging wave reached the
+      // barrier last once the steps were down to the finalize chain): it goes into LDS here -- the items of this step read the
+      // other parity's buffer -- and the row of diagonal k+2 is requested into the same registers.
+      if (!(DRNA_SKIP & 32) && wave == w_pl) {
+        if (k + 1 < n) {
+          int* dst = sm.plist[(k + 1) & 1];
+          dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
+          if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = pl3;
+          if (lane == 0) { sm.pcnt[(k + 1) & 1] = pl_cnt; sm.qhead[(k + 1) & 1] = 0; sm.qtile[(k + 1) & 1] = 0; }
         }
+        if (k + 2 < n) pl_request(k + 2);
       }
+      const bool job_q5 = !(DRNA_SKIP & 64) && wave == w_q5 && k - 3 >= TURN + 2;
       double qx0 = 0.0, qx1 = 0.0, qx2 = 0.0, qx3 = 0.0;
       if (job_q5) {
         const int j = k - 3, top = j - TURN - 1;                   // i = 1 .. top
@@ -783,8 +797,12 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
           const double aK = aKn + dfar_cur;        // (zero for a cell without far split points)
           const int t = pair_type(si, sj);
+#ifdef DRNA_PF_CREG
+          const double cTau = eTau, cMLc = eMLc, cMLi = eMLi, cb1 = b1, csc2 = sc2;
+#else
           const double cTau = sm.xc[as_vector(8)], cMLc = sm.xc[as_vector(9)], cMLi = sm.xc[as_vector(10)], cb1 = sm.xc[as_vector(11)],
                        csc2 = sm.xc[as_vector(12)];
+#endif
           const double tau = t > 2 ? cTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
@@ -834,12 +852,6 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         }
       }
       TLMARK2(1, k);
-      if (job_pl) {
-        int* dst = sm.plist[(k + 1) & 1];
-        dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
-        if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = pl3;
-        if (lane == 0) { sm.pcnt[(k + 1) & 1] = pl_cnt; sm.qhead[(k + 1) & 1] = 0; sm.qtile[(k + 1) & 1] = 0; }
-      }
       if (job_q5) {
         // q5[j] = q5[j-1] scale[1] + sum_i q5[i-1] qb[i,j] expExt(i,j): four strided terms per lane, fixed-order wave sum
         const int j = k - 3, top = j - TURN - 1;
