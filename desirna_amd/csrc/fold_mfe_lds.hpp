@@ -530,6 +530,14 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   // +1.33 for the cell finalize alone)
   const int w_et = NB > 3 ? 2 : w_tab;
 
+#ifdef DRNA_TL
+  long long* ptl2 = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
+  const bool ptl2_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0 && tid == 0;
+#define PTL2(x) do { if (ptl2_on) ptl2[256 + (x)] = (long long)wall_clock64(); } while (0)
+#else
+#define PTL2(x) do { } while (0)
+#endif
+  PTL2(0);
   if (DUAL) {
     // round prologue for the helper workgroup, first thing: the pairing codes of this round (masked positions = 4), then the
     // flag -- the helper builds the pairable lists of the diagonals from PL_D1 on while this workgroup fills its tables
@@ -539,6 +547,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     __syncthreads();
     if (tid == 0) { st_agent(lk.flagA, lk.base + TURN); sm.sync_fail = 0; }
   }
+  PTL2(1);
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
   for (int k = tid; k < 4 * RS; k += NT) sm.dml[k] = INF;
   for (int k = tid; k < 32 * RS; k += NT) { sm.wring[k] = INF * 256; sm.ciring[k] = INF; }   // idle tower entries read row 0
@@ -586,9 +595,11 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     sm.xtab[SM::XT_MM23 + k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
   }
   for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
+  PTL2(2);
   // (two-workgroup kernel: the rows from PL_D1 on are the helper's, see mfe_pl_row)
   for (int d = TURN + 1 + wave; d < (DUAL ? min(n, PL_D1) : n); d += NW) mfe_pl_row<DUAL>(sm, T, PL, PLX, ld, n, d, lane, TermAU);
   __syncthreads();
+  PTL2(3);
   // tables and pairable list of the first diagonal
   if (aw < 0) {
     const int d = TURN + 1;
@@ -886,6 +897,13 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
   int32_t* PL = base + 3 * tab;      // compacted pairable-cell lists, one row per diagonal
   int32_t* PLX = base + 1 * tab;     // their staged (1,2) / (2,1) loop energies
 
+#ifdef DRNA_TL
+  // phase marks of sequence 0's (main) workgroup (tools/timeline.py mfe): kernel entry, fill done, traceback done (steps start at
+  // TURN + 1: slots 0 .. 3 of every event row are free); PTL2 in mfe_fill_lds: the parts of the first round's prologue
+  long long* ptl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
+  const bool ptl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0 && tid == 0;
+  if (ptl_on) ptl[0] = (long long)wall_clock64();
+#endif
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
   for (int k = tid; k < 128; k += NT) {
     sm.mmH[k] = T.mmH[k]; sm.mmI[k] = T.mmI[k]; sm.mm1n[k] = T.mm1n[k];
@@ -920,6 +938,9 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
     for (int k = tid; k < n; k += NT) sm.ssw[k] = '.';
     lk.base = dual_base(lk.epoch, round);
     mfe_fill_lds<NT, DUAL>(sm, A, Wc, EXT, PL, PLX, lk);           // ends with a barrier
+#ifdef DRNA_TL
+    if (ptl_on && round == 0) ptl[1] = (long long)wall_clock64();
+#endif
     if (DUAL && sm.sync_fail) { status = ST_SYNC; break; }
     // traceback by TB_WAVES waves working from one queue of sectors in LDS (TbShared): entry 0 = the whole exterior interval
     constexpr int TB_WAVES = NT / WAVE < 8 ? NT / WAVE : 8;
@@ -932,6 +953,9 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
     __syncthreads();
     if (!(DRNA_SKIP & 256) && wave_id() < TB_WAVES) (void)mfe_traceback_q(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT, TbShared<MfeFastSmem<NT>>{sm});
     __syncthreads();
+#ifdef DRNA_TL
+    if (ptl_on && round == 0) ptl[2] = (long long)wall_clock64();
+#endif
     if (tid == 0) {
       if (round == 0) A.Emfe[r] = sm.f5[n];
       sm.flag = (!(DRNA_SKIP & 256) && sm.tbq[3] == 2) ? 1 : 0;

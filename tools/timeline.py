@@ -34,6 +34,12 @@ t3 = buf.view(np.int64)[60 * 256:76 * 256].reshape(16, 256).astype(np.float64) /
 if not MFE and t[0, 0, 0] > 0:
     print("PF main workgroup: kernel entry -> first step %.2f us, steps %.2f us, last barrier -> Z stored %.2f us" %
           (t[0, 0, TURN1] - t[0, 0, 0], t[0, 0, 2] - t[0, 0, TURN1], t[0, 0, 3] - t[0, 0, 2]))
+if MFE and t[0, 0, 0] > 0:
+    print("MFE main workgroup: kernel entry -> first step %.2f us, steps %.2f us, traceback %.2f us" %
+          (t[0, 0, TURN1] - t[0, 0, 0], t[0, 0, 1] - t[0, 0, TURN1], t[0, 0, 2] - t[0, 0, 1]))
+    e = t[0, 0, 0]
+    print("   prologue, from kernel entry: tables + sequence in LDS %.2f, codes published %.2f, LDS tables of the fill %.2f, list rows %.2f, first step %.2f us" %
+          (t[0, 1, 0] - e, t[0, 1, 1] - e, t[0, 1, 2] - e, t[0, 1, 3] - e, t[0, 0, TURN1] - e))
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     ks = np.arange(lo, hi)
     t0 = t[:, 0, ks].min(axis=0)                      # first wave out of the barrier
