@@ -446,6 +446,9 @@ template <class SM> struct TbShared {
   __device__ __forceinline__ bool failed() const { return *reinterpret_cast<volatile int*>(&sm.tbq[3]) == 2; }
 };
 
+#ifdef DRNA_TL_TB
+static __device__ long long* drna_tl_tb_ptr = nullptr;      // diagnostics (tools/timeline.py mfe, TL_TB=1): where block 0's traceback waves report
+#endif
 template <class SM, class FMLACC, class QUEUE>
 __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const int32_t* __restrict__ Wc,
                                        const FMLACC FML, const int32_t* __restrict__ EXT, QUEUE Q) {
@@ -478,6 +481,9 @@ __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const 
     tb_L[rnd] = L;
   }
   // one sector: an exterior interval (ml 0), a multiloop segment (ml 1); returns false when a table value cannot be reproduced
+#ifdef DRNA_TL_TB
+  int tb_events = 0;
+#endif
   Q.init(n);
   auto sector = [&](int i, int j, const int ml) -> bool {
     bool have_pair = false;
@@ -560,6 +566,9 @@ __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const 
     }
     // ---- pair (i,j): hairpin, interior (p ascending, q descending), multiloop
     while (have_pair) {
+#ifdef DRNA_TL_TB
+      tb_events++;
+#endif
       if (lane == 0) { sm.ssw[i - 1] = '('; sm.ssw[j - 1] = ')'; }
       const int d = j - i;
       const int t = pair_type(sm.Sp[i], sm.Sp[j]);
@@ -622,10 +631,26 @@ __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const 
     return true;
   };
   int qi = 0, qj = 0, qml = 0;
+#ifdef DRNA_TL_TB
+  long long tb_t0 = (long long)wall_clock64(), tb_busy = 0;
+  int tb_sectors = 0;
+#endif
   while (Q.pop(qi, qj, qml)) {
+#ifdef DRNA_TL_TB
+    const long long s0 = (long long)wall_clock64();
+#endif
     if (!sector(qi, qj, qml)) { Q.fail(); ok = false; break; }
     Q.done_one();
+#ifdef DRNA_TL_TB
+    tb_busy += (long long)wall_clock64() - s0; tb_sectors++;
+#endif
   }
+#ifdef DRNA_TL_TB
+  if (lane == 0 && blockIdx.x == 0 && drna_tl_tb_ptr) {
+    long long* o = drna_tl_tb_ptr + 512 + 8 * wave_id();
+    o[0] = tb_t0; o[1] = (long long)wall_clock64(); o[2] = tb_busy; o[3] = tb_sectors; o[4] = tb_events;
+  }
+#endif
   return ok && !Q.failed();
 }
 

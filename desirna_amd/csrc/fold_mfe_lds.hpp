@@ -951,6 +951,10 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
       sm.tbq[0] = 0; sm.tbq[1] = 1; sm.tbq[2] = 1; sm.tbq[3] = 0;
     }
     __syncthreads();
+#ifdef DRNA_TL_TB
+    if (blockIdx.x == 0 && tid == 0) drna_tl_tb_ptr = round == 0 ? ptl : nullptr;
+    __syncthreads();
+#endif
     if (!(DRNA_SKIP & 256) && wave_id() < TB_WAVES) (void)mfe_traceback_q(sm, A, Wc, FmlLds<NT>{&sm, n}, EXT, TbShared<MfeFastSmem<NT>>{sm});
     __syncthreads();
 #ifdef DRNA_TL

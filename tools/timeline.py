@@ -40,6 +40,12 @@ if MFE and t[0, 0, 0] > 0:
     e = t[0, 0, 0]
     print("   prologue, from kernel entry: tables + sequence in LDS %.2f, codes published %.2f, LDS tables of the fill %.2f, list rows %.2f, first step %.2f us" %
           (t[0, 1, 0] - e, t[0, 1, 1] - e, t[0, 1, 2] - e, t[0, 1, 3] - e, t[0, 0, TURN1] - e))
+if MFE and os.environ.get("TL_TB"):
+    raw = buf.view(np.int64)
+    print("traceback of sequence 0 (-DDRNA_TL -DDRNA_TL_TB): per wave start, end (us from the fill's end), busy us, sectors, pair events")
+    for w in range(8):
+        o = raw[512 + 8 * w: 512 + 8 * w + 5]
+        print("   wave %d: %.2f .. %.2f  busy %.2f  sectors %d  events %d" % (w, o[0] / 100.0 - t[0, 0, 1], o[1] / 100.0 - t[0, 0, 1], o[2] / 100.0, o[3], o[4]))
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     ks = np.arange(lo, hi)
     t0 = t[:, 0, ks].min(axis=0)                      # first wave out of the barrier
