@@ -463,22 +463,10 @@ __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const 
   constexpr int NRND = (NPLAN + WAVE - 1) / WAVE;
   int tb_shape[NRND], tb_L[NRND];
 #pragma unroll
-  for (int rnd = 0; rnd < NRND; rnd++) {
+  for (int rnd = 0; rnd < NRND; rnd++) {        // (packed on the host, tables.hpp: sixteen independent loads, first used by the first scan)
     const int k = rnd * WAVE + lane;
-    int u1 = 0, u2 = 0;
-    if (k < NPLAN) { u1 = P.tb_u1[k]; u2 = P.tb_u2[k]; }
-    const int nl = u1 > u2 ? u1 : u2, ns = u1 > u2 ? u2 : u1;
-    int kind, L = 0;
-    if (nl == 0) kind = PK_STACK;
-    else if (ns == 0) { kind = nl == 1 ? PK_BULGE1 : PK_BULGEN; L = T.bulge[nl]; }
-    else if (ns == 1 && nl == 1) kind = PK_INT11;
-    else if (ns == 1 && nl == 2) kind = u1 == 1 ? PK_INT21 : PK_INT12;
-    else if (ns == 1) { kind = PK_1XN; L = T.interior[nl + 1] + min(T.max_ninio, (nl - ns) * T.ninio); }
-    else if (ns == 2 && nl == 2) kind = PK_INT22;
-    else if (ns == 2 && nl == 3) { kind = PK_INT23; L = T.interior[5] + T.ninio; }
-    else { kind = PK_GENERIC; L = T.interior[nl + ns] + min(T.max_ninio, (nl - ns) * T.ninio); }
-    tb_shape[rnd] = u1 | (u2 << 8) | (kind << 16);
-    tb_L[rnd] = L;
+    tb_shape[rnd] = k < NPLAN ? P.tb_shape[k] : (PK_STACK << 16);
+    tb_L[rnd] = k < NPLAN ? P.tb_L[k] : 0;
   }
   // one sector: an exterior interval (ml 0), a multiloop segment (ml 1); returns false when a table value cannot be reproduced
 #ifdef DRNA_TL_TB

@@ -43,6 +43,7 @@ struct Plan {
   int seg[PK_NKINDS + 1];  // entries of kind k are [seg[k], seg[k+1])
   // canonical traceback order (p ascending, q descending): SURVEY App. A.4
   int tb_u1[NPLAN], tb_u2[NPLAN];
+  int tb_shape[NPLAN], tb_L[NPLAN];   // ... packed for the traceback's scan: u1 | u2 << 8 | kind << 16, and the candidate's size term
   // The generic entries are ordered by (u1+u2, u1): entries of one loop size read CONSECUTIVE cells of one table row, so a
   // lane can fetch them 16 bytes at a time.  Slots of two (fp64 tables) and of four (int32 tables) consecutive entries:
   // first entry and number of entries (a slot never crosses a loop size).
@@ -290,7 +291,13 @@ inline std::string build_tables(const int32_t* b, int n_int32, HostTables& T) {
   e = 0;
   for (int u1 = 0; u1 <= MAXLOOP; u1++)       // p ascending
     for (int u2 = 0; u1 + u2 <= MAXLOOP; u2++) {  // q descending
-      P.tb_u1[e] = u1; P.tb_u2[e] = u2; e++;
+      const int k = kind_of(u1, u2), nl = std::max(u1, u2), ns = std::min(u1, u2);
+      int L = 0;
+      if (k == PK_BULGE1 || k == PK_BULGEN) L = M.bulge[nl];           // (the device tables' values: what the fill added)
+      else if (k == PK_1XN) L = M.interior[nl + 1] + std::min(M.max_ninio, (nl - ns) * M.ninio);
+      else if (k == PK_INT23) L = M.interior[5] + M.ninio;
+      else if (k == PK_GENERIC) L = M.interior[nl + ns] + std::min(M.max_ninio, (nl - ns) * M.ninio);
+      P.tb_u1[e] = u1; P.tb_u2[e] = u2; P.tb_shape[e] = u1 | (u2 << 8) | (k << 16); P.tb_L[e] = L; e++;
     }
   return "";
 }
