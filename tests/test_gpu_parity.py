@@ -829,6 +829,30 @@ def test_lost_pf_helper_costs_milliseconds(eng400, oracle):
     assert abs(float(ref["Epf"][0]) - oracle.pf(seqs[0])) < EPF_TOL_ORACLE
 
 
+def test_tile_products_give_the_same_bits_whoever_computes_them(eng400, oracle):
+    """The far multiloop split points of the partition function are 4 x 4 tile products (fold_pf_lds.hpp): computed by
+    the helper workgroup in small batches, by the main workgroup's sweep waves otherwise -- same device functions, so Epf must
+    agree BITWISE between the two, at lengths that leave ragged tiles, a single block distance with a far range (21 .. 24 nt:
+    the first tiles) or none at all; and with the oracle to 1e-9."""
+    from desirna_amd import engine as E
+    rng = np.random.default_rng(4242)
+    try:
+        for L in (20, 21, 22, 23, 24, 37, 64, 97, 131, 150, 199, 200):
+            seqs = [_rand(rng, L) for _ in range(4)] + ["GC" * (L // 2) + "A" * (L % 2)]
+            eng400.set_targets(["." * L])
+            eng400.set_option("pf_helper", 1)
+            a = eng400.score_batch(seqs, E.NEED_PF)
+            assert eng400.get_option("last_workgroups") == 2 * len(seqs), L           # main + helper per fold
+            eng400.set_option("pf_helper", 0)
+            b = eng400.score_batch(seqs, E.NEED_PF)
+            assert eng400.get_option("last_workgroups") == len(seqs), L
+            assert (a["Epf"].view(np.int64) == b["Epf"].view(np.int64)).all(), L
+            for k in (0, len(seqs) - 1):
+                assert abs(float(a["Epf"][k]) - oracle.pf(seqs[k])) < EPF_TOL_ORACLE, (L, k)
+    finally:
+        eng400.set_option("pf_helper", 1)
+
+
 def test_repeated_lost_partners_switch_the_multi_workgroup_paths_off_for_a_while(eng400):
     """A GPU shared with another process loses partners call after call, and every lost call costs its wait budget before it is
     redone (round-2 advisor finding).  Three fallbacks in a row: the engine folds with one workgroup per fold for the next 1000

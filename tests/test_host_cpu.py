@@ -148,3 +148,26 @@ def test_tile_product_schedule_never_reads_an_unfinished_operand():
     W = int(re.search(r"#define DRNA_PKT_W (\d+)", src).group(1)); L = int(re.search(r"#define DRNA_PKT_L (\d+)", src).group(1))
     assert m.check(W, L) == 0 and m.check(W, 3) == 0 and m.check(8, 3) == 0
     assert m.check(W, 2) > 0
+
+
+def test_tile_geometry_of_the_partition_function_counts_every_split_point_once():
+    """fold_pf_lds.hpp cuts a cell's multiloop split points into the far range of its 4 x 4 tile (one matrix-product chain, by the
+    helper workgroup or by the main workgroup's sweep waves) and at most PKE + 3 near ones at either end (tools/kt_geometry.py
+    restates the index arithmetic): every split point exactly once, the near slots fit their four rows, a tile's operands are
+    final when its first step comes, and the helper's flag covers the cells the main workgroup reads after it -- for the shipped
+    slack and for lengths that leave ragged tiles; a far range that starts one split point early must be caught."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kt_geometry", os.path.join(ROOT, "tools", "kt_geometry.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    src = open(os.path.join(ROOT, "desirna_amd", "csrc", "fold_pf_lds.hpp")).read()
+    pke = int(re.search(r"#define DRNA_PKE (\d+)", src).group(1))
+    assert pke >= 4
+    assert "const int c = a + B, m_lo = 4 * a + 9 + PKE, m_hi = 4 * c - 3 - PKE;" in src          # what far_range() restates
+    assert "nl = 4 * a + 4 + PKE - i; nh = j - 4 * c - 1 + PKE;" in src                            # ... and near_counts()
+    for n in (200, 199, 64, 37, 21, 9):
+        assert m.check(n, pke) == 0, n
+    good = m.far_range
+    m.far_range = lambda a, B, p: (good(a, B, p)[0] - 1, good(a, B, p)[1])
+    assert m.check(64, pke) > 0
+    m.far_range = good
+    assert m.check(64, 3) > 0          # less slack than the main workgroup's four-step window needs
