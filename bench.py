@@ -394,7 +394,8 @@ def main():
     ap.add_argument("--seqs", choices=["uniform", "design"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc-loop", action="store_true", help="skip the end-to-end Monte-Carlo loop figure (mc_loop)")
-    ap.add_argument("--r-sweep", action="store_true", help="add the replicas-per-call sweep (32 / 64 / 128 / 256) to the line (N = 1)")
+    ap.add_argument("--r-sweep", action="store_true", help="(default at N = 1 since round 4; kept for old command lines)")
+    ap.add_argument("--no-r-sweep", action="store_true", help="skip the replicas-per-call sweep (32 / 64 / 128 / 256) of the N = 1 line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))        # before torch / HIP are touched in this process
@@ -604,7 +605,7 @@ def main():
                 raise SystemExit("bench: GPU results differ from the oracle")
         if not args.no_mc_loop and not shared_card:
             out["mc_loop"] = mc_loop_block(eng, target, R, args.exchange_every, out["value"] / world, tk["total"])
-        if args.r_sweep and world == 1:
+        if not args.no_r_sweep and world == 1 and not shared_card:
             out["r_sweep"] = r_sweep_block(target, local_rank)
         print(json.dumps(out))
     if multi:

@@ -962,6 +962,9 @@ def test_bench_line_carries_parity_roofline_baseline_and_the_monte_carlo_loop():
     assert mc["scored_sequences_per_s"] > 0 and mc["iterations"] == 20 and mc["replicas"] == 64 and mc["L"] == 200
     assert mc["ms_per_iteration"] >= mc["kernel_ms_per_iteration"] > 0 and mc["accepted"] + mc["rejected"] == 20 * 64
     assert "workgroups <= " in d["cus_occupied"]["resident_check"]
+    rs = {x["R"]: x for x in d["r_sweep"]}                     # replicas per call: more folds per call must not cost throughput
+    assert sorted(rs) == [32, 64, 128, 256] and all(x["sync_fallbacks"] == 0 for x in rs.values())
+    assert rs[128]["replica_folds_per_s"] > rs[64]["replica_folds_per_s"] and rs[256]["replica_folds_per_s"] > 0.95 * rs[128]["replica_folds_per_s"]
 
 
 def test_one_launch_form_equals_the_two_launches(eng400, oracle, eterna_targets):
