@@ -103,6 +103,15 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     if (lane == 0) { sm.pcnt[par] = cnt; sm.qhead[par] = 0; }
   };
 
+#ifdef DRNA_TL
+  // timeline of sequence 0's helper (tools/timeline.py mfe): per step, clocks of wave 0 at the top and after the inbound copy, of
+  // wave 1 after the outbound stores, of the first and the last worker wave after their items (rows 49 .. 53 of the main role's mark table)
+  long long* htl = reinterpret_cast<long long*>(A.ws + (long long)r * A.ws_stride + 2LL * A.ld * A.ld);
+  const bool htl_on = r == 0 && lane == 0;
+#define HTL(ev, D) do { if (htl_on) htl[((49 + (ev)) << 8) + (D)] = (long long)wall_clock64(); } while (0)
+#else
+#define HTL(ev, D) do { } while (0)
+#endif
   bool failed = false;
   for (int round = 0; round <= A.pk_rounds; round++) {
     const int base = dual_base(lk.epoch, round);
@@ -128,6 +137,7 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     for (int D = DUAL_D0; D <= n + 1; D++) {         // steps D = n, n+1 only ship the last diagonal and raise its flag
       const int par = D & 1, ncell = n - D;
       if (wave == 0) {
+        HTL(0, D);
         // ---- inbound: rows of diagonal D+1-DLAG (needed from diagonal D+1 on); the flag was read at the end of the
         // previous step, so the only latency in the step is one round of loads
         if (D + 1 < n) {
@@ -150,9 +160,11 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
             }
           }
         }
+        HTL(1, D);
         fa = ld_agent(lk.flagA);                       // for the next step (left in flight across the barrier)
       } else if (wave == 2) {
         if (D + 1 < n) prepare(D + 1);               // tables of the next diagonal (sequence only: no wait)
+        HTL(5, D);
       } else if (wave == 1) {
         // ---- outbound: the flag of diagonal D-2 (its minima were stored during the previous step: they have landed by
         // now, so the wait is short), then the minima of diagonal D-1 (reset for diagonal D+1)
@@ -167,17 +179,40 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
             sm.accK[ps][i] = INF; sm.accI[ps][i] = INF;
           }
         }
+        HTL(2, D);
       } else if (D < n) {
         // ---- workers: K items (32-cell blocks of split sweeps), then the far-shape items of the pairable cells
         const int pcnt = __builtin_amdgcn_readfirstlane(sm.pcnt[par]);
-        const int nK = (DRNA_SKIP & 8) ? 0 : (ncell + 31) >> 5, nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);      // (DRNA_SKIP: timing builds)
+        // a late diagonal has one to three 32-cell blocks and up to 180 split points per cell: as one item per block one worker wave
+        // walked a 1.5 - 1.9 us chain while twelve idled, and from diagonal ~125 on the main role waited for its helper in every step
+        // (tools/timeline.py mfe).  The split points of a block go to 1, 2, 4 or 8 items as the cells get fewer (minima are order-free)
+#ifndef DRNA_HKS
+#define DRNA_HKS 3
+#endif
+        const int kssh = !DRNA_HKS ? 0 : DRNA_HKS == 2 ? (ncell > 128 ? 1 : ncell > 64 ? 2 : 3) : DRNA_HKS == 3 ? (ncell > 96 ? 0 : ncell > 64 ? 1 : 2) : ncell > 128 ? 0 : ncell > 64 ? 1 : ncell > 32 ? 2 : 3;
+        const int k_lo = TURN + 1 + KEDGE, k_hi = D - TURN - 2 - KEDGE;
+        const int k_per = (((k_hi - k_lo + 1 + (1 << kssh) - 1) >> kssh) + 3) & ~3;       // split points per item
+        const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);      // (DRNA_SKIP: timing builds)
         const int nItems = __builtin_amdgcn_readfirstlane(nK + nE);
         for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
-          if (it < nK) mfe_k_item(sm, it, D, n, ncell, par, 0, lane, TURN + 1 + KEDGE, D - TURN - 2 - KEDGE);
-          else mfe_e_item<E_FAR>(sm, it - nK, D, par, pcnt, 0, lane, TermAU, e_bulge1, e_int23);
+          if (it < nK) {
+            const int lo = k_lo + (it & ((1 << kssh) - 1)) * k_per;
+            mfe_k_item(sm, it >> kssh, D, n, ncell, par, 0, lane, lo, min(k_hi, lo + k_per - 1));
+          } else mfe_e_item<E_FAR>(sm, it - nK, D, par, pcnt, 0, lane, TermAU, e_bulge1, e_int23);
         }
+        if (wave == 3) HTL(3, D);
+        if (wave == NT / WAVE - 1) HTL(4, D);
+        HTL(6 + wave, D);
       }
+      // an LDS-only barrier: the inbound wave's flag load (for the next step) really stays in flight across it -- behind a
+      // draining barrier that cross-XCD round trip was the helper's step (tools/timeline.py mfe: everything done at +1.1 us, step
+      // 1.9 us, and from diagonal ~125 on the main role waited for its helper in every step).  Nothing else needs the drain:
+      // the outbound wave drains its own stores before it raises their flag, the inbound rows are in LDS, the workers store to LDS
+#ifdef DRNA_HELPER_DRAIN
       __syncthreads();
+#else
+      lds_barrier();
+#endif
       if (sm.failr[D & 1]) { failed = true; break; }         // (the other parity's word is the one step D+1 may write)
     }
     if (failed) break;

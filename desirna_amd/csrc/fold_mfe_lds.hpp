@@ -244,8 +244,13 @@ __device__ __forceinline__ void mfe_k_edge_item(SM& sm, int it, int d, int n, in
 constexpr int ECOARSE = 32;   // at most this many pairable cells on the diagonal: coarse E items
 constexpr int ESH = 10, EPB = 13;   // one-workgroup kernel: shapes per E item; E items per block of 64 pairable cells (4 classes x 3 parts + small shapes)
 constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge class (u = 2 .. DLAG-3) and per 1xn class (u = 3 .. DLAG-4)
+#ifndef DRNA_EFAR_PARTS
+#define DRNA_EFAR_PARTS 2
+#endif
+constexpr int EFAR_PARTS = DRNA_EFAR_PARTS;        // items per class of far shapes (helper workgroup): 23 live shapes in 1 x 29 / 2 x 12 / 3 x 8
+constexpr int EFAR_NSH = EFAR_PARTS == 1 ? 29 : EFAR_PARTS == 2 ? 12 : 8;
 template <int MODE>
-__device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 : MODE == E_COARSE ? 5 : EPB; }
+__device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 * EFAR_PARTS : MODE == E_COARSE ? 5 : EPB; }
 
 // candidates of NSH consecutive shapes of one class, starting at table entry `first` (entries that are padding in this
 // table read the INF row); bulges: ring word >> 8 + size term; 1xn loops: + the inner pair's 1xn mismatch
@@ -327,8 +332,13 @@ __device__ __forceinline__ void mfe_e_item(SM& sm, int e, int d, int par, int pc
                    mfe_e_class<ESH, true>(sm, ring, par, first + 2 * ESH, lane)) + sm.mm1n[ij];
     } else v = mfe_e_small(sm, ring, d, par, qc, pe, ij, e_bulge1, e_int23);
   } else if (MODE == E_FAR) {
-    if (x < 2) v = mfe_e_class<29, false>(sm, ring, par, x * 32, lane) + outer_b;
-    else v = mfe_e_class<27, true>(sm, ring, par, x * 32, lane) + sm.mm1n[ij];
+    // the 23 far shapes of a class (bulges u = DLAG-2 .. 30, 1xn loops u = DLAG-3 .. 29) in EFAR_PARTS items: as one item per class
+    // (29 table entries, the near ones reading the INF row) an item was a 1.3 - 1.8 us chain, and at late diagonals, where a step has
+    // a dozen items for thirteen worker waves, the helper's step was its longest item (tools/timeline.py mfe)
+    const int cls = EFAR_PARTS == 1 ? x : x / EFAR_PARTS, part = EFAR_PARTS == 1 ? 0 : x - EFAR_PARTS * cls;
+    const int first = cls * 32 + (EFAR_PARTS == 1 ? 0 : (cls < 2 ? NEAR_B : NEAR_I) + part * EFAR_NSH);
+    if (cls < 2) v = mfe_e_class<EFAR_NSH, false>(sm, ring, par, first, lane) + outer_b;
+    else v = mfe_e_class<EFAR_NSH, true>(sm, ring, par, first, lane) + sm.mm1n[ij];
   } else {
     if (x == 0) v = min(mfe_e_class<NEAR_B, false>(sm, ring, par, 0, lane), mfe_e_class<NEAR_B, false>(sm, ring, par, 32, lane)) + outer_b;
     else v = min(min(mfe_e_class<NEAR_I, true>(sm, ring, par, 64, lane), mfe_e_class<NEAR_I, true>(sm, ring, par, 96, lane)) + sm.mm1n[ij],
@@ -702,6 +712,9 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         int bK = pfK, bI = pfI;
         if (DUAL && d >= DUAL_D0) {                              // (before that diagonal the helper has nothing to add)
           if (!have) {                                           // not fetched ahead: wait for the helper here
+#ifdef DRNA_TL
+            if (mtl_on && tid == 0) { long long* cnt = mtl + 12287; cnt[0] += 1ll << (8 * (k / 25)); }      // (timeline builds: steps that met the helper late)
+#endif
             if (!sm.sync_fail && !wait_flag_wave(lk.flagB, lk.base + d)) sm.sync_fail = 1;
             const bool on = i >= 1 && i <= ncell;
             bK = on ? ld_agent(xk + d * XP + i) : INF;
@@ -902,7 +915,7 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
   // TURN + 1: slots 0 .. 3 of every event row are free); PTL2 in mfe_fill_lds: the parts of the first round's prologue
   long long* ptl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
   const bool ptl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0 && tid == 0;
-  if (ptl_on) ptl[0] = (long long)wall_clock64();
+  if (ptl_on) { ptl[0] = (long long)wall_clock64(); ptl[12287] = 0; }
 #endif
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];
   for (int k = tid; k < 128; k += NT) {

@@ -40,6 +40,22 @@ if MFE and t[0, 0, 0] > 0:
     e = t[0, 0, 0]
     print("   prologue, from kernel entry: tables + sequence in LDS %.2f, codes published %.2f, LDS tables of the fill %.2f, list rows %.2f, first step %.2f us" %
           (t[0, 1, 0] - e, t[0, 1, 1] - e, t[0, 1, 2] - e, t[0, 1, 3] - e, t[0, 0, TURN1] - e))
+if MFE:
+    late = int(buf.view(np.int64)[12287])
+    print("steps in which the main role had to wait for its helper (its results were not there a step ahead), by 25 steps:",
+          [(late >> (8 * b)) & 255 for b in range(8)])
+if MFE:
+    raw64 = np.zeros(22 * 256, dtype=np.int64)
+    eng._L.drna_debug_read_mfe_ws(eng._h, 2 * tab + 2 * (49 << 8), 2 * raw64.size, raw64.ctypes.data)
+    h = raw64.reshape(22, 256).astype(np.float64) / 100.0
+    print("helper of sequence 0, per step (us from its top): inbound copy done, outbound stores done, next diagonal's tables done, first / last worker wave done, step length")
+    for lo, hi in ((20, 72), (72, 125), (125, 150), (150, 175), (175, 197)):
+        ks = np.arange(lo, hi)
+        print("   steps %3d..%3d: inbound +%.2f  outbound +%.2f  tables +%.2f  workers +%.2f / +%.2f  step %.2f   (main role's step %.2f)" %
+              (lo, hi, (h[1, ks] - h[0, ks]).mean(), (h[2, ks] - h[0, ks]).mean(), (h[5, ks] - h[0, ks]).mean(), (h[3, ks] - h[0, ks]).mean(), (h[4, ks] - h[0, ks]).mean(),
+               np.diff(h[0, lo:hi + 1]).mean(), np.diff(t[0, 0, lo:hi + 1]).mean()))
+        wk = h[6 + 3:6 + 16][:, ks] - h[0, ks]
+        print("        worker waves 3..15 done at: " + " ".join("%.2f" % x for x in wk.mean(axis=1)) + "   last of them +%.2f" % wk.max(axis=0).mean())
 if MFE and os.environ.get("TL_TB"):
     raw = buf.view(np.int64)
     print("traceback of sequence 0 (-DDRNA_TL -DDRNA_TL_TB): per wave start, end (us from the fill's end), busy us, sectors, pair events")
