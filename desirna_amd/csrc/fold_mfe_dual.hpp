@@ -103,6 +103,16 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     if (lane == 0) { sm.pcnt[par] = cnt; sm.qhead[par] = 0; }
   };
 
+  // the main role's pairable lists from diagonal PL_D1 on (mfe_pl_row): it reads the first of them after it has seen a flag of the
+  // round, which is raised behind a drained barrier.  The first round's pairing codes are the sequence itself: its lists are
+  // built at once, while the main role is still filling its tables (the later rounds' codes come from the main role)
+  auto build_lists = [&]() {
+    for (int d = PL_D1 + wave; d < n; d += NT / WAVE) mfe_pl_row<true>(sm, T, PL, PLX, A.ld, n, d, lane, TermAU);
+  };
+  for (int k = tid; k <= n + 1; k += NT) sm.Sp[k] = k >= 1 && k <= n ? sm.S[k] : (unsigned char)4;
+  __syncthreads();
+  build_lists();
+
 #ifdef DRNA_TL
   // timeline of sequence 0's helper (tools/timeline.py mfe): per step, clocks of wave 0 at the top and after the inbound copy, of
   // wave 1 after the outbound stores, of the first and the last worker wave after their items (rows 49 .. 53 of the main role's mark table)
@@ -122,11 +132,11 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
     }
     __syncthreads();
     if (sm.fail) break;
-    for (int k = tid; k <= n + 1; k += NT) sm.Sp[k] = (unsigned char)ld_agent(lk.xs + k);
-    __syncthreads();
-    // the main role's pairable lists from diagonal PL_D1 on (mfe_pl_row): it reads the first of them after it has seen a flag of this
-    // round, which is raised behind the barrier below
-    for (int d = PL_D1 + wave; d < n; d += NT / WAVE) mfe_pl_row<true>(sm, T, PL, PLX, A.ld, n, d, lane, TermAU);
+    if (round > 0) {
+      for (int k = tid; k <= n + 1; k += NT) sm.Sp[k] = (unsigned char)ld_agent(lk.xs + k);
+      __syncthreads();
+      build_lists();
+    }
     drain_vmem();
     __syncthreads();
     if (wave == 0 && DUAL_D0 < n) prepare(DUAL_D0);

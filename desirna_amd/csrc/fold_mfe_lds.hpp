@@ -248,7 +248,7 @@ constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge c
 #define DRNA_EFAR_PARTS 2
 #endif
 constexpr int EFAR_PARTS = DRNA_EFAR_PARTS;        // items per class of far shapes (helper workgroup): 23 live shapes in 1 x 29 / 2 x 12 / 3 x 8
-constexpr int EFAR_NSH = EFAR_PARTS == 1 ? 29 : EFAR_PARTS == 2 ? 12 : 8;
+constexpr int EFAR_NSH = EFAR_PARTS == 1 ? 29 : (33 - DLAG + EFAR_PARTS - 1) / EFAR_PARTS;   // 33 - DLAG far shapes per class
 template <int MODE>
 __device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 * EFAR_PARTS : MODE == E_COARSE ? 5 : EPB; }
 
@@ -474,7 +474,7 @@ __device__ __forceinline__ void mfe_e_item_rows(SM& sm, int e, int d, int par, i
 // the two-workgroup kernel the main role builds the rows below PL_D1 only and its HELPER, which has nothing to do until the main
 // role's tenth diagonal, the rest (AGENT: stored write-through, read sc1): the main role's prologue is 16 us shorter.
 #ifndef DRNA_PL_D1
-#define DRNA_PL_D1 28
+#define DRNA_PL_D1 16
 #endif
 constexpr int PL_D1 = DRNA_PL_D1;
 constexpr int DUAL_D0 = 2 * TURN + 3;      // first diagonal the helper contributes to (a far shape's inner pair is >= 5 diagonals back)
@@ -551,11 +551,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   if (DUAL) {
     // round prologue for the helper workgroup, first thing: the pairing codes of this round (masked positions = 4), then the
     // flag -- the helper builds the pairable lists of the diagonals from PL_D1 on while this workgroup fills its tables
+    // (the stores travel while this workgroup fills its LDS tables; the flag follows once they have landed)
     int32_t* xs = lk.xs;
     for (int k = tid; k <= n + 1; k += NT) st_agent(xs + k, (int32_t)sm.Sp[k]);
-    drain_vmem();
-    __syncthreads();
-    if (tid == 0) { st_agent(lk.flagA, lk.base + TURN); sm.sync_fail = 0; }
+    if (tid == 0) sm.sync_fail = 0;
   }
   PTL2(1);
   // ---- prologue: constant tables, and the compacted list of pairable cells of every diagonal (HBM/L2)
@@ -605,9 +604,14 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     sm.xtab[SM::XT_MM23 + k] = sm.mm23[k] - ((k >> 4) > 2 ? TermAU : 0);
   }
   for (int j = tid; j <= n && j <= TURN + 1; j += NT) sm.f5[j] = 0;
+  if (DUAL) {
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0) st_agent(lk.flagA, lk.base + TURN);
+  }
   PTL2(2);
-  // (two-workgroup kernel: the rows from PL_D1 on are the helper's, see mfe_pl_row)
-  for (int d = TURN + 1 + wave; d < (DUAL ? min(n, PL_D1) : n); d += NW) mfe_pl_row<DUAL>(sm, T, PL, PLX, ld, n, d, lane, TermAU);
+  // (two-workgroup kernel: the rows from PL_D1 on are the helper's, see mfe_pl_row; this workgroup's own rows stay in its L2)
+  for (int d = TURN + 1 + wave; d < (DUAL ? min(n, PL_D1) : n); d += NW) mfe_pl_row<false>(sm, T, PL, PLX, ld, n, d, lane, TermAU);
   __syncthreads();
   PTL2(3);
   // tables and pairable list of the first diagonal
@@ -647,14 +651,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     auto pl_request = [&](const int dn) {
       const int32_t* row = PL + dn * ld;
       const int32_t* rowx = PLX + dn * ld;
-      pw_cnt = DUAL ? ld_agent(row + ld - 1) : row[ld - 1];       // (two-workgroup kernel: the helper may have written the row)
+      const bool ag = DUAL && dn >= PL_D1;                        // (two-workgroup kernel: the helper's rows)
+      pw_cnt = ag ? ld_agent(row + ld - 1) : row[ld - 1];
       const int nch = (n - dn + WAVE - 1) >> 6;                 // chunks the diagonal's cells can fill (uniform, known without the count)
 #pragma unroll
       for (int c = 0; c < 4; c++)
         if (c < nch) {
           const int o = min(lane + c * WAVE, ld - 1);
-          pw[c] = DUAL ? ld_agent(row + o) : row[o];
-          px[c] = DUAL ? ld_agent(rowx + o) : rowx[o];
+          pw[c] = ag ? ld_agent(row + o) : row[o];
+          px[c] = ag ? ld_agent(rowx + o) : rowx[o];
         }
     };
     if (wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
