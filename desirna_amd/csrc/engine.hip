@@ -466,7 +466,7 @@ static int pair_blocks_per_cu(drna_engine* e) {
   if (e->pair_blocks_per_cu < 0) {
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mfe_dual_kernel<1024>, 1024, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pf_lds_kernel<1024>, 1024, 0) != hipSuccess) b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pf_lds_kernel<1024, false>, 1024, 0) != hipSuccess) b = 0;      // (the instance of the helper launches)
     e->pair_blocks_per_cu = std::min(a, b);
   }
   return e->pair_blocks_per_cu;
@@ -619,7 +619,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
     else if (pf_help)
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
+      hipLaunchKernelGGL((pf_lds_kernel<1024, false>), dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
     else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
       hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{});
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);

@@ -452,9 +452,11 @@ __device__ __forceinline__ void pf_kfar_helper(const PfArgs& A, const EvalArgs& 
   }
 }
 
-template <int NT>
 // bx_in / helper_in: the caller's own block -> (sequence slot, role) mapping (fold_fused.hpp); -1 = this kernel's grid (2 bx + role
-// with a helper workgroup per sequence, bx without)
+// with a helper workgroup per sequence, bx without).  TILES = false: an instance for launches WITH helper workgroups only -- it
+// holds no tile code in its sweep loop, so the cell finalize can keep its five constants in registers (with the tile code the
+// kernel is at the register limit and they spill into the finalize chain; read from LDS they cost the floor build 12 us)
+template <int NT, bool TILES = true>
 __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const EvalArgs& EV, int bx_in = -1, int helper_in = -1) {
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
@@ -702,7 +704,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   // 0.56 / 0.61 / 0.63 / 0.65 ms for 0 / 1 / 2 / 4 products carried, against 0.54.)
   auto run_tiles = [&](const int d) {
     const int Bmax = (n - 1) >> 2, Bt = ((d + 3) >> 2) + 1, ph = (d + 3) & 3;
-    if ((DRNA_SKIP & (8 | 512)) || hm || Bt < KT_BMIN || Bt > Bmax) return;         // (512: timing build without the far split points)
+    if (!TILES || (DRNA_SKIP & (8 | 512)) || hm || Bt < KT_BMIN || Bt > Bmax) return;         // (512: timing build without the far split points)
     const int cnt = Bmax - Bt + 1, per = (cnt + 3) >> 2, a0 = ph * per;
     const int nT = __builtin_amdgcn_readfirstlane(max(0, min(cnt, a0 + per) - a0));
     for (int it = queue_pop(&sm.qtile[d & 1], lane); it < nT; it = queue_pop(&sm.qtile[d & 1], lane)) {
@@ -797,12 +799,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
           const double aK = aKn + dfar_cur;        // (zero for a cell without far split points)
           const int t = pair_type(si, sj);
-#ifdef DRNA_PF_CREG
-          const double cTau = eTau, cMLc = eMLc, cMLi = eMLi, cb1 = b1, csc2 = sc2;
-#else
-          const double cTau = sm.xc[as_vector(8)], cMLc = sm.xc[as_vector(9)], cMLi = sm.xc[as_vector(10)], cb1 = sm.xc[as_vector(11)],
-                       csc2 = sm.xc[as_vector(12)];
-#endif
+          const double cTau = TILES ? sm.xc[as_vector(8)] : eTau, cMLc = TILES ? sm.xc[as_vector(9)] : eMLc,
+                       cMLi = TILES ? sm.xc[as_vector(10)] : eMLi, cb1 = TILES ? sm.xc[as_vector(11)] : b1, csc2 = TILES ? sm.xc[as_vector(12)] : sc2;
           const double tau = t > 2 ? cTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
@@ -942,10 +940,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   }
 }
 
-template <int NT>
+template <int NT, bool TILES = true>
 __global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A, EvalArgs EV) {      // EV.n_targets > 0 (helper launches only): E(targets) too
   __shared__ PfFastSmem<NT> sm;
-  pf_lds_body<NT>(sm, A, EV);
+  if (!TILES && !A.helper) return;               // (the engine launches this instance with helper workgroups only)
+  pf_lds_body<NT, TILES>(sm, A, EV);
 }
 
 }  // namespace drna
