@@ -16,8 +16,8 @@ if has tests; then echo "== pytest gpu"; timeout -k 10 900 python -m pytest test
 if has bench; then
   echo "== bench"; timeout -k 10 400 python bench.py --steps $STEPS --warmup 5 > $O/bench_uniform.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
   cat $O/bench_uniform.json
-  timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline > $O/bench_design.json 2>/dev/null || exit 1
-  DRNA_PF_HELPER=0 timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > $O/bench_nohelper.json 2>/dev/null || exit 1
+  timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline --no-r-sweep > $O/bench_design.json 2>/dev/null || exit 1
+  DRNA_PF_HELPER=0 timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-r-sweep > $O/bench_nohelper.json 2>/dev/null || exit 1
   DRNA_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_gloo2_rehearsal.json 2> $O/bench_gloo2.err || { tail -5 $O/bench_gloo2.err; }
   DRNA_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --scaling strong --steps 20 --warmup 3 > $O/bench_gloo2_strong_rehearsal.json 2> $O/bench_gloo2_strong.err || { tail -5 $O/bench_gloo2_strong.err; }
   timeout -k 10 300 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-mc-loop --r-sweep > $O/bench_rsweep.json 2>/dev/null || exit 1
@@ -31,7 +31,7 @@ for f in ('bench_uniform','bench_design','bench_nohelper','bench_gloo2_rehearsal
 fi
 if has prof; then
   echo "== rocprof kernel trace"
-  rm -rf gpurun_out/prof; (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof" -o r4 -- python3 "$REPO/bench.py" --steps $STEPS --warmup 5 --no-cpu-baseline --no-mc-loop > "$REPO/$O/bench_prof.json" 2> "$REPO/$O/prof.err") || exit 1
+  rm -rf gpurun_out/prof; (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof" -o r4 -- python3 "$REPO/bench.py" --steps $STEPS --warmup 5 --no-cpu-baseline --no-mc-loop --no-r-sweep > "$REPO/$O/bench_prof.json" 2> "$REPO/$O/prof.err") || exit 1
   for f in $(find gpurun_out/prof -name "*kernel_stats*.csv"); do cp $f gpurun_out/rocprofv3_kernel_stats.csv; cp $f $O/rocprofv3_kernel_stats.csv; head -4 $f; done
 fi
 if has pmc; then
@@ -39,7 +39,7 @@ if has pmc; then
   pass() { # name counters...
     name=$1; shift
     rm -rf gpurun_out/pmc_$name
-    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/pmc_$name" -o $name -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-mc-loop > /dev/null 2> "$REPO/gpurun_out/pmc_$name.err") || { tail -3 gpurun_out/pmc_$name.err; return 1; }
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/pmc_$name" -o $name -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-mc-loop --no-r-sweep > /dev/null 2> "$REPO/gpurun_out/pmc_$name.err") || { tail -3 gpurun_out/pmc_$name.err; return 1; }
     rm -rf gpurun_out/cal_$name
     (cd /tmp && timeout -k 10 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/cal_$name" -o $name -- "$REPO/tools/pmc_calib" > /dev/null 2> "$REPO/gpurun_out/cal_$name.err") || { tail -3 gpurun_out/cal_$name.err; return 1; }
   }
