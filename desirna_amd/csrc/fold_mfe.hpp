@@ -635,7 +635,7 @@ __device__ __forceinline__ bool mfe_traceback_q(SM& sm, const MfeArgs& A, const 
   }
 #ifdef DRNA_TL_TB
   if (lane == 0 && blockIdx.x == 0 && drna_tl_tb_ptr) {
-    long long* o = drna_tl_tb_ptr + 512 + 8 * wave_id();
+    long long* o = drna_tl_tb_ptr + (72 << 8) + 8 * wave_id();       // (row 72 of the mark table: beyond the main role's and the helper's rows)
     o[0] = tb_t0; o[1] = (long long)wall_clock64(); o[2] = tb_busy; o[3] = tb_sectors; o[4] = tb_events;
   }
 #endif

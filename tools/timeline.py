@@ -57,10 +57,11 @@ if MFE:
         wk = h[6 + 3:6 + 16][:, ks] - h[0, ks]
         print("        worker waves 3..15 done at: " + " ".join("%.2f" % x for x in wk.mean(axis=1)) + "   last of them +%.2f" % wk.max(axis=0).mean())
 if MFE and os.environ.get("TL_TB"):
-    raw = buf.view(np.int64)
+    raw = np.zeros(64, dtype=np.int64)
+    eng._L.drna_debug_read_mfe_ws(eng._h, 2 * tab + 2 * (72 << 8), 2 * raw.size, raw.ctypes.data)
     print("traceback of sequence 0 (-DDRNA_TL -DDRNA_TL_TB): per wave start, end (us from the fill's end), busy us, sectors, pair events")
     for w in range(8):
-        o = raw[512 + 8 * w: 512 + 8 * w + 5]
+        o = raw[8 * w: 8 * w + 5]
         print("   wave %d: %.2f .. %.2f  busy %.2f  sectors %d  events %d" % (w, o[0] / 100.0 - t[0, 0, 1], o[1] / 100.0 - t[0, 0, 1], o[2] / 100.0, o[3], o[4]))
 for lo, hi in ((10, 40), (40, 72), (72, 110), (110, 150), (150, 196)):
     ks = np.arange(lo, hi)
