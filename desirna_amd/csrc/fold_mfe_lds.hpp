@@ -55,8 +55,7 @@ struct MfeFastSmem : MfeSmemCore<MFE_FAST_NMAX> {
   int tbq[4];                    // sector queue of the traceback (TbShared, fold_mfe.hpp)
   int etab[2][128];              // the same shapes as seen from one diagonal: byte offset of the inner pair's ring cell
                                  // for column 0 | size term << 16 (shapes without an inner pair yet point at the INF row)
-  int tw_L[32];                  // generic interior size term by total loop size s (INF below 6)
-  int tower_tab[2][32][6];       // per residue: ring byte offsets A, B; asymmetry term; birth floor; interior size term; pad
+  int twc[32][2];                // by total loop size s: {asymmetry term of the two new shapes (2, s-2) (s-2, 2), size term (INF below 6)} (mfe_tower2_step)
 };
 
 // compact triangle: row d (4 <= d <= n-1) holds cells i = 1..n-d
@@ -135,7 +134,7 @@ __device__ __forceinline__ void mfe_prepare_tower_tab(SM& sm, int d, int tid, in
 }
 template <int NT>
 __device__ __forceinline__ void mfe_prepare_tables(MfeFastSmem<NT>& sm, int d, int tid, int ninio, int max_ninio, int emode = E_ALL) {
-  mfe_prepare_tower_tab(sm, d, tid, ninio, max_ninio);
+  (void)ninio; (void)max_ninio;      // (the tower step needs no per-diagonal table any more: mfe_tower2_step)
   if (tid >= 0 && tid < WAVE) mfe_prepare_etab(sm, d, tid, emode);
 }
 
@@ -165,6 +164,52 @@ __device__ __forceinline__ int mfe_tower_step(const SM& sm, int (&G)[GSLOTS], in
     acc = min(acc, G[r] + lane_table(eL, r));
   }
   return acc;
+}
+
+// ---- tower step with entries indexed by the LOOP SIZE s, not by the inner diagonal (the form fold_pf_lds.hpp has since round 3).
+// G_s(i,j) = min over the generic shapes of size s of (inner pair's ring word + asymmetry term) obeys
+//     G_s(i,j) = min( G_{s-2}(i+1,j-1), min(X[d'][i+3], X[d'][i+s-1]) + asym[s-4] ),   d' = d - 2 - s,
+// and the step of a tower from diagonal d-2 to d moves every minimum from size s-2 to s: in descending order of s that is
+// G[q] <- min(G[q-1], ...), a shift.  Per entry everything is a compile-time constant except the ring row (d - 2 - s) & 31: three
+// VALU for the address, two ring reads with immediate column offsets, one broadcast read of {asym, size term}, an add, two mins
+// and an add (the table-driven form: five v_readlane, two reads, six VALU per entry, and a table a finalize wave rebuilt every
+// diagonal).  A wave owns the sizes of ONE parity (s and s-2 share registers) and ONE diagonal parity (a tower has one): it
+// works every other step and carries TSL_M = 14 minima; from diagonal 10 on (the first generic shape) three 64-slot blocks cover
+// the cells of a 200-nt fold: twelve roles for its twelve sweep waves.  Rows of diagonals that do not exist yet read as INF
+// (the ring is INF-initialised and a row's first tenant is written after its last such read).
+constexpr int TSL_M = 14;          // entries per tower wave: s = 4 + sigma + 2 q, q = 0 .. 13 (s <= 30)
+template <class SM, int SIG, int Q0, int Q1>
+__device__ __forceinline__ void mfe_tower2_part(const SM& sm, int (&G)[TSL_M], int dv, int i4, int cbase, int& acc) {
+  const char* ring = reinterpret_cast<const char*>(sm.ciring);
+  int a[Q1 - Q0], b[Q1 - Q0], cx[Q1 - Q0], cy[Q1 - Q0];
+#pragma unroll
+  for (int q = Q1 - 1; q >= Q0; q--) {
+    const int s = 4 + SIG + 2 * q;
+    if (s > 30) continue;
+    const int va = ((dv - s) & 31) * (SM::RS * 4) + i4;          // dv = d + 30 in a VGPR: row (d - 2 - s) & 31
+    a[q - Q0] = *reinterpret_cast<const int*>(ring + va + 12);
+    b[q - Q0] = *reinterpret_cast<const int*>(ring + va + (s - 1) * 4);
+    cx[q - Q0] = *reinterpret_cast<const int*>(ring + cbase + s * 8);      // the entry's two constants (same address in every lane)
+    cy[q - Q0] = *reinterpret_cast<const int*>(ring + cbase + s * 8 + 4);
+  }
+#pragma unroll
+  for (int q = Q1 - 1; q >= Q0; q--) {
+    const int s = 4 + SIG + 2 * q;
+    if (s > 30) continue;
+    const int v = min(a[q - Q0], b[q - Q0]) + cx[q - Q0];
+    G[q] = q > 0 ? min(G[q - 1], v) : v;
+    acc = min(acc, G[q] + cy[q - Q0]);
+  }
+}
+template <class SM, int SIG>
+__device__ __forceinline__ int mfe_tower2_step(const SM& sm, int (&G)[TSL_M], int dv, int i4) {
+  // byte offset of the constants from the ring's start, kept out of the compiler's sight (a literal address costs a v_mov per read)
+  const int cbase = as_vector((int)(reinterpret_cast<const char*>(&sm.twc[0][0]) - reinterpret_cast<const char*>(sm.ciring)));
+  int acc0 = INF_DEV, acc1 = INF_DEV, acc2 = INF_DEV;
+  mfe_tower2_part<SM, SIG, 9, 14>(sm, G, dv, i4, cbase, acc0);     // descending: the upper entries read their predecessors first
+  mfe_tower2_part<SM, SIG, 4, 9>(sm, G, dv, i4, cbase, acc1);
+  mfe_tower2_part<SM, SIG, 0, 4>(sm, G, dv, i4, cbase, acc2);
+  return min(min(acc0, acc1), acc2);
 }
 
 // ---- work items shared by the one-workgroup kernel and by the two roles of the two-workgroup kernel (fold_mfe_dual.hpp)
@@ -530,9 +575,19 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   const int off0 = (NB * WAVE - n) / 2;
   const int NA = NW - NB;                  // sweep waves
   const int aw = wave - NB;                // index among the sweep waves (< 0: finalize wave)
-  const int NG = NA / NB;                  // sweep waves pinned to one tower block (>= 3 for n <= 256, NT = 1024)
-  const int my_tb = aw >= 0 ? aw / NG : NB, my_g = aw >= 0 ? aw - my_tb * NG : 0;
-  const bool pinned = aw >= 0 && my_tb < NB;
+  // Tower roles (mfe_tower2_step).  Generic loops exist from diagonal 10 on, where n - 10 cells are left: NBT = ceil((n - 10) / 64)
+  // blocks of 64 tower slots starting at slot T0 cover them for the rest of the fill (the slot range only shrinks).  1024 threads:
+  // a block gets four waves, parity of the loop size x parity of the diagonal -- such a wave works every other step; n = 200:
+  // three blocks, twelve roles, every sweep wave has one.  Smaller workgroups (CPU emulation, n <= 64): two waves per block, both
+  // diagonal parities each.
+  constexpr bool TWO_PAR = NT < 1024;
+  const int nT = n - 10, NBT = nT > 0 ? (nT + WAVE - 1) / WAVE : 0;
+  const int T0 = max(0, off0 + 5 - (NBT * WAVE - nT) / 2);
+  int my_tb = -1, my_sig = 0, my_pm = 0;             // block, parity of s, mask of the diagonal parities taken (0: no tower role)
+  if (aw >= 0) {
+    if (TWO_PAR) { if (aw < 2 * NBT) { my_tb = aw >> 1; my_sig = aw & 1; my_pm = 3; } }
+    else if (aw < 4 * NBT) { my_tb = aw >> 2; const int x = (aw + my_tb) & 3; my_sig = x & 1; my_pm = 1 << (x >> 1); }
+  }
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;
   // the shape table of the next diagonal goes to a wave of its own when there is one without a side job (n > 128: wave 2): with
@@ -595,7 +650,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     }
     sm.eshape_rows[x] = s_ | (kind_ << 5) | (u1_ << 8) | (L_ << 16);
   }
-  for (int k = tid; k < 32; k += NT) sm.tw_L[k] = k >= 6 && k <= 30 ? T.interior[k] : INF;
+  for (int k = tid; k < 32; k += NT) {
+    sm.twc[k][0] = k >= 4 && k <= 30 ? min(max_ninio, (k - 4) * ninio) : INF;
+    sm.twc[k][1] = k >= 6 && k <= 30 ? T.interior[k] : INF;
+  }
   using SM = MfeFastSmem<NT>;
   for (int k = tid; k < 64; k += NT) sm.xtab[SM::XT_STACK + k] = sm.stack[k] - ((k & 7) > 2 ? TermAU : 0);
   for (int k = tid; k < 1024; k += NT) sm.xtab[SM::XT_INT11 + k] = sm.int11[k] - (((k >> 4) & 7) > 2 ? TermAU : 0);
@@ -779,8 +837,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         // once the outermost tower blocks hold no cell any more (n = 200: from diagonal 72 on) their finalize waves, which keep the
         // list staging and the exterior column, are done long before the centre blocks' (+0.9 against +1.6 us): the tables go to them
         const bool outer_idle = NB > 3 && (d >> 1) + off0 >= WAVE;
-        const int wt = outer_idle ? 0 : w_tab, we = outer_idle ? NB - 1 : w_et;
-        if (wave == wt) mfe_prepare_tower_tab(sm, k + 1, lane, ninio, max_ninio);
+        const int we = outer_idle ? NB - 1 : w_et;
         if (wave == we) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
       }
       if (wave == w_q5 && k - 3 >= TURN + 2) {
@@ -816,11 +873,20 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     }
   } else {
     // ================= sweep waves
-    int GE[GSLOTS], GO[GSLOTS];
+    int GE[TSL_M], GO[TSL_M];
 #pragma unroll
-    for (int r = 0; r < GSLOTS; r++) { GE[r] = INF; GO[r] = INF; }
+    for (int r = 0; r < TSL_M; r++) { GE[r] = INF; if (TWO_PAR) GO[r] = INF; }
     const int e_bulge1 = keep_i32(T.bulge[1]), e_int23 = keep_i32(T.interior[5] + ninio);
-    const int item_rank = NB < 3 ? aw : my_tb == 0 ? my_g : my_tb == NB - 1 ? NG + my_g : !pinned ? aw : 2 * NG + (aw - NG);
+    // Static dealing of the main role's items (two-workgroup kernel).  A tower wave works every other step: the waves whose towers
+    // rest in this step come first, among them the waves without a tower role, then the outer blocks' (whose towers die first)
+    const int blk_ord = my_tb < 0 ? 0 : my_tb == 0 ? 0 : my_tb == NBT - 1 ? min(1, NBT - 1) : my_tb + 1;      // 0, 2 .. NBT-1, 1 -> outer blocks first
+    const int n_free = NA - (TWO_PAR ? 2 : 4) * NBT;          // sweep waves without a tower role
+    auto item_rank_of = [&](const int par) -> int {
+      if (TWO_PAR) return aw;
+      if (my_tb < 0) return aw - 4 * NBT;
+      const bool rests = !((my_pm >> par) & 1);
+      return n_free + (rests ? 0 : 2 * NBT) + 2 * blk_ord + my_sig;
+    };
 
     for (int k = TURN + 1; k <= n; k++) {
       MTLMARK(0, k);
@@ -828,14 +894,20 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
         const int lo = sh + off0, hi = ncell + sh + off0 - 1;
-        const int tb_lo = lo >> 6, tb_hi = hi >> 6;
         // ---- T: tower step
-        if (!(DRNA_SKIP & 1) && pinned && my_tb >= tb_lo && my_tb <= tb_hi) {
-          int i = my_tb * WAVE + lane + 1 - sh - off0;
+        if (!(DRNA_SKIP & 1) && ((my_pm >> par) & 1) && d >= 10) {
+          const int blo = T0 + my_tb * WAVE;                        // the block's slots blo .. blo + 63; the diagonal's cells lo .. hi
+          int i = blo + lane + 1 - sh - off0;
           i = i < 1 ? 1 : (i > ncell ? ncell : i);
-          const int accG = par ? mfe_tower_step(sm, GO, par, i * 4, my_g, NG, lane)
-                               : mfe_tower_step(sm, GE, par, i * 4, my_g, NG, lane);
-          atomicMin(&sm.accG[par][my_tb * WAVE + lane], accG);
+          const int dv = as_vector(d + 30), i4 = i * 4;
+          if (blo <= hi && blo + WAVE - 1 >= lo) {
+            int accG = INF;
+            if constexpr (TWO_PAR) {
+              if (par) accG = my_sig ? mfe_tower2_step<MfeFastSmem<NT>, 1>(sm, GO, dv, i4) : mfe_tower2_step<MfeFastSmem<NT>, 0>(sm, GO, dv, i4);
+            }
+            if (!TWO_PAR || !par) accG = my_sig ? mfe_tower2_step<MfeFastSmem<NT>, 1>(sm, GE, dv, i4) : mfe_tower2_step<MfeFastSmem<NT>, 0>(sm, GE, dv, i4);
+            atomicMin(&sm.accG[par][blo + lane], accG);
+          }
         }
         STAMP(0);
         MTLMARK(1, k);
@@ -858,7 +930,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         // one-workgroup kernel: items from the work queue (LDS counter).  Main role of the two-workgroup kernel: the few
         // items left (edge split points, near shapes) are dealt statically, waves of the outer tower blocks -- whose towers
         // die first -- before those of the centre blocks: no queue pops (a pop is an LDS atomic round trip of ~400 cycles)
-        int it = DUAL ? item_rank : queue_pop(&sm.qhead[par], lane);
+        int it = DUAL ? item_rank_of(par) : queue_pop(&sm.qhead[par], lane);
         for (; it < nItems; it = DUAL ? it + NA : queue_pop(&sm.qhead[par], lane)) {
           STAMP(6);
           if (it < nK) {
