@@ -588,6 +588,15 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     if (TWO_PAR) { if (aw < 2 * NBT) { my_tb = aw >> 1; my_sig = aw & 1; my_pm = 3; } }
     else if (aw < 4 * NBT) { my_tb = aw >> 2; const int x = (aw + my_tb) & 3; my_sig = x & 1; my_pm = 1 << (x >> 1); }
   }
+  // The pairable-list row of the next diagonal is staged into LDS by two SWEEP waves taking turns (block 0's even-size waves: the
+  // one whose towers rest in a step requests the row after next, and writes it first thing in the following step, in which it is
+  // active).  On a finalize wave the staging was +0.5 us on the cell finalize -- the pole of every step in which the outermost
+  // block still holds cells (tools/timeline.py mfe: +2.04 us against +1.27).  Small workgroups (emulation) keep it on a finalize wave.
+#ifndef DRNA_SWEEP_STAGE
+#define DRNA_SWEEP_STAGE 1
+#endif
+  const bool sweep_stage = DRNA_SWEEP_STAGE && !TWO_PAR && NBT >= 1;
+  const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;
   // the shape table of the next diagonal goes to a wave of its own when there is one without a side job (n > 128: wave 2): with
@@ -720,7 +729,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
           px[c] = ag ? ld_agent(rowx + o) : rowx[o];
         }
     };
-    if (wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
+    if (!sweep_stage && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       MTLMARK(0, k);
@@ -746,7 +755,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       // k+2 is requested into the same registers.  The exterior column's cells are requested here and consumed after the cell
       // finalize.
       int fx[4];
-      if (wave == w_pl) {
+      if (!sweep_stage && wave == w_pl) {
         if (k + 1 < n) {
           const int dn = k + 1;
           int* dst = sm.plist[dn & 1];
@@ -888,8 +897,38 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
       return n_free + (rests ? 0 : 2 * NBT) + 2 * blk_ord + my_sig;
     };
 
+    int sw[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, sw_cnt = 0;            // the staged list row (stager waves)
+    auto st_request = [&](const int dn) {
+      const int32_t* row = PL + dn * ld;
+      const int32_t* rowx = PLX + dn * ld;
+      const bool ag = DUAL && dn >= PL_D1;                        // (two-workgroup kernel: the helper's rows)
+      sw_cnt = ag ? ld_agent(row + ld - 1) : row[ld - 1];
+      const int nch = (n - dn + WAVE - 1) >> 6;
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (c < nch) {
+          const int o = min(lane + c * WAVE, ld - 1);
+          sw[c] = ag ? ld_agent(row + o) : row[o];
+          sx[c] = ag ? ld_agent(rowx + o) : rowx[o];
+        }
+    };
+    // (the wave that is active in the first step writes the second diagonal's row at its top: requested here)
+    if (stager && ((my_pm >> ((TURN + 1) & 1)) & 1) && TURN + 2 < n) st_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       MTLMARK(0, k);
+      if (stager && k < n) {
+        if ((my_pm >> (k & 1)) & 1) {                              // active in this step: the row requested a step ago goes into LDS
+          if (k + 1 < n) {
+            const int dn = k + 1;
+            int* dst = sm.plist[dn & 1];
+            int* dxe = sm.xe[dn & 1];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (lane + c * WAVE < MfeFastSmem<NT>::NL) { dst[lane + c * WAVE] = sw[c]; dxe[lane + c * WAVE] = sx[c]; }
+            if (lane == 0) { sm.pcnt[dn & 1] = sw_cnt; sm.qhead[dn & 1] = 0; }
+          }
+        } else if (k + 2 < n) st_request(k + 2);                   // resting: request the row after next
+      }
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
