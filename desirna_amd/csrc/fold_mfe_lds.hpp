@@ -592,10 +592,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   // one whose towers rest in a step requests the row after next, and writes it first thing in the following step, in which it is
   // active).  On a finalize wave the staging was +0.5 us on the cell finalize -- the pole of every step in which the outermost
   // block still holds cells (tools/timeline.py mfe: +2.04 us against +1.27).  Small workgroups (emulation) keep it on a finalize wave.
-#ifndef DRNA_SWEEP_STAGE
-#define DRNA_SWEEP_STAGE 1
+#ifndef DRNA_MFE_SWEEP_STAGE
+#define DRNA_MFE_SWEEP_STAGE 1
 #endif
-  const bool sweep_stage = DRNA_SWEEP_STAGE && !TWO_PAR && NBT >= 1;
+  const bool sweep_stage = DRNA_MFE_SWEEP_STAGE && !TWO_PAR && NBT >= 1;
   const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;

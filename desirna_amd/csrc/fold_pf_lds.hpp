@@ -564,6 +564,18 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     else if (aw < 4 * NBT) { my_tb = aw >> 2; const int x = (aw + my_tb) & 3; my_sig = x & 1; my_pm = 1 << (x >> 1); }
   }
   const int w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
+  // Option: the pairable-list row of the next diagonal staged into LDS by two SWEEP waves taking turns (block 0's even-size waves:
+  // the one whose towers rest in a step requests the row after next and writes it first thing in the following step, in which it
+  // is active), as fold_mfe_lds.hpp does it, where the staging sat on a finalize wave's cell finalize.  With a helper workgroup the late rows are the helper's: the first of them is requested at step
+  // PFL_D1 - 2, after the finalize waves have waited for the helper's flag of diagonal KT_D0 and a barrier has passed.
+  // -- measured and switched off here: the partition function's early steps are item-bound on exactly those waves (0.430 -> 0.438 ms
+  // at R = 64, 0.531 -> 0.542 at R = 128).
+#ifndef DRNA_PF_SWEEP_STAGE
+#define DRNA_PF_SWEEP_STAGE 0
+#endif
+  static_assert(PFL_D1 - 2 >= KT_D0, "a sweep wave reads a helper-built row only after the finalize waves have seen the helper's flag");
+  const bool sweep_stage = DRNA_PF_SWEEP_STAGE && !TWO_PAR && NBT >= 1 && !(DRNA_SKIP & 32);
+  const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
 
   if (aw < 0) {
     const int d = TURN + 1;
@@ -716,6 +728,9 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
 
   if (aw < 0) {
     // ================= finalize waves: diagonal d = k-1 at step k
+    // (the cell finalize's constants in registers: values of THIS branch only, read from LDS once, so that they do not occupy
+    // registers -- or spill slots reloaded inside the finalize chain -- through the sweep waves' loop, tile code or not)
+    double fTau = sm.xc[as_vector(8)], fMLc = sm.xc[as_vector(9)], fMLi = sm.xc[as_vector(10)], fb1 = sm.xc[as_vector(11)], fsc2 = sm.xc[as_vector(12)];
     // the staged list row travels in registers from the step that requests it to the next one (wave w_pl)
     int pl_cnt = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
     auto pl_request = [&](const int dn) {
@@ -734,7 +749,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
       }
     };
-    if (!(DRNA_SKIP & 32) && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
+    if (!(DRNA_SKIP & 32) && !sweep_stage && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       TLMARK(0, k);
@@ -746,7 +761,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       // come from beyond this XCD's L2, ~2 us, and with the request at the top of the SAME step the staging wave reached the
       // barrier last once the steps were down to the finalize chain): it goes into LDS here -- the items of this step read the
       // other parity's buffer -- and the row of diagonal k+2 is requested into the same registers.
-      if (!(DRNA_SKIP & 32) && wave == w_pl) {
+      if (!(DRNA_SKIP & 32) && !sweep_stage && wave == w_pl) {
         if (k + 1 < n) {
           int* dst = sm.plist[(k + 1) & 1];
           dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
@@ -799,8 +814,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
           const double aKn = d >= 2 * TURN + 3 ? (sm.partK[par][0][tid] + sm.partK[par][1][tid]) + (sm.partK[par][2][tid] + sm.partK[par][3][tid]) : 0.0;
           const double aK = aKn + dfar_cur;        // (zero for a cell without far split points)
           const int t = pair_type(si, sj);
-          const double cTau = TILES ? sm.xc[as_vector(8)] : eTau, cMLc = TILES ? sm.xc[as_vector(9)] : eMLc,
-                       cMLi = TILES ? sm.xc[as_vector(10)] : eMLi, cb1 = TILES ? sm.xc[as_vector(11)] : b1, csc2 = TILES ? sm.xc[as_vector(12)] : sc2;
+          const double cTau = fTau, cMLc = fMLc, cMLi = fMLi, cb1 = fb1, csc2 = fsc2;
           const double tau = t > 2 ? cTau : 1.0;
           const int ij = t * 16 + si1 * 4 + sj1, rt = rtype_of(t);
           const int info = t ? (rt << 4) | (sjp << 2) | sim : 0;
@@ -878,8 +892,32 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     double GE[TSL], GO[TSL];
 #pragma unroll
     for (int q = 0; q < TSL; q++) { GE[q] = 0.0; if (TWO_PAR) GO[q] = 0.0; }
+    int s_cnt = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;                  // the staged list row (stager waves)
+    auto st_request = [&](const int dn) {
+      const int32_t* row = PL + dn * ld;
+      if (hm && dn >= PFL_D1) {                                       // the helper's rows: sc1
+        s_cnt = ld_agent(row + ld - 1);
+        s0 = ld_agent(row + lane); s1 = ld_agent(row + lane + WAVE); s2 = ld_agent(row + lane + 2 * WAVE);
+        s3 = ld_agent(row + min(lane + 3 * WAVE, ld - 1));
+      } else {
+        s_cnt = row[ld - 1];
+        s0 = row[lane]; s1 = row[lane + WAVE]; s2 = row[lane + 2 * WAVE]; s3 = row[min(lane + 3 * WAVE, ld - 1)];
+      }
+    };
+    // (the wave that is active in the first step writes the second diagonal's row at its top: requested here)
+    if (stager && ((my_pm >> ((TURN + 1) & 1)) & 1) && TURN + 2 < n) st_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       TLMARK(0, k);
+      if (stager && k < n) {
+        if ((my_pm >> (k & 1)) & 1) {                                // active in this step: the row requested a step ago goes into LDS
+          if (k + 1 < n) {
+            int* dst = sm.plist[(k + 1) & 1];
+            dst[lane] = s0; dst[lane + WAVE] = s1; dst[lane + 2 * WAVE] = s2;
+            if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = s3;
+            if (lane == 0) { sm.pcnt[(k + 1) & 1] = s_cnt; sm.qhead[(k + 1) & 1] = 0; sm.qtile[(k + 1) & 1] = 0; }
+          }
+        } else if (k + 2 < n) st_request(k + 2);                     // resting: request the row after next
+      }
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
