@@ -196,10 +196,7 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
         // a late diagonal has one to three 32-cell blocks and up to 180 split points per cell: as one item per block one worker wave
         // walked a 1.5 - 1.9 us chain while twelve idled, and from diagonal ~125 on the main role waited for its helper in every step
         // (tools/timeline.py mfe).  The split points of a block go to 1, 2, 4 or 8 items as the cells get fewer (minima are order-free)
-#ifndef DRNA_HKS
-#define DRNA_HKS 3
-#endif
-        const int kssh = !DRNA_HKS ? 0 : DRNA_HKS == 2 ? (ncell > 128 ? 1 : ncell > 64 ? 2 : 3) : DRNA_HKS == 3 ? (ncell > 96 ? 0 : ncell > 64 ? 1 : 2) : ncell > 128 ? 0 : ncell > 64 ? 1 : ncell > 32 ? 2 : 3;
+        const int kssh = ncell > 96 ? 0 : ncell > 64 ? 1 : 2;
         const int k_lo = TURN + 1 + KEDGE, k_hi = D - TURN - 2 - KEDGE;
         const int k_per = (((k_hi - k_lo + 1 + (1 << kssh) - 1) >> kssh) + 3) & ~3;       // split points per item
         const int nK = (DRNA_SKIP & 8) ? 0 : ((ncell + 31) >> 5) << kssh, nE = (DRNA_SKIP & 2) ? 0 : e_items_per_block<E_FAR>() * ((pcnt + WAVE - 1) >> 6);      // (DRNA_SKIP: timing builds)
@@ -218,11 +215,7 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
       // draining barrier that cross-XCD round trip was the helper's step (tools/timeline.py mfe: everything done at +1.1 us, step
       // 1.9 us, and from diagonal ~125 on the main role waited for its helper in every step).  Nothing else needs the drain:
       // the outbound wave drains its own stores before it raises their flag, the inbound rows are in LDS, the workers store to LDS
-#ifdef DRNA_HELPER_DRAIN
-      __syncthreads();
-#else
       lds_barrier();
-#endif
       if (sm.failr[D & 1]) { failed = true; break; }         // (the other parity's word is the one step D+1 may write)
     }
     if (failed) break;

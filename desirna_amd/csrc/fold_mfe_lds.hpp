@@ -289,10 +289,7 @@ __device__ __forceinline__ void mfe_k_edge_item(SM& sm, int it, int d, int n, in
 constexpr int ECOARSE = 32;   // at most this many pairable cells on the diagonal: coarse E items
 constexpr int ESH = 10, EPB = 13;   // one-workgroup kernel: shapes per E item; E items per block of 64 pairable cells (4 classes x 3 parts + small shapes)
 constexpr int NEAR_B = DLAG - 4, NEAR_I = DLAG - 6;   // near shapes per bulge class (u = 2 .. DLAG-3) and per 1xn class (u = 3 .. DLAG-4)
-#ifndef DRNA_EFAR_PARTS
-#define DRNA_EFAR_PARTS 2
-#endif
-constexpr int EFAR_PARTS = DRNA_EFAR_PARTS;        // items per class of far shapes (helper workgroup): 23 live shapes in 1 x 29 / 2 x 12 / 3 x 8
+constexpr int EFAR_PARTS = 2;        // items per class of far shapes (helper workgroup): 23 live shapes in 1 x 29 / 2 x 12 / 3 x 8
 constexpr int EFAR_NSH = EFAR_PARTS == 1 ? 29 : (33 - DLAG + EFAR_PARTS - 1) / EFAR_PARTS;   // 33 - DLAG far shapes per class
 template <int MODE>
 __device__ __forceinline__ constexpr int e_items_per_block() { return MODE == E_NEAR ? 2 : MODE == E_FAR ? 4 * EFAR_PARTS : MODE == E_COARSE ? 5 : EPB; }
@@ -592,10 +589,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   // one whose towers rest in a step requests the row after next, and writes it first thing in the following step, in which it is
   // active).  On a finalize wave the staging was +0.5 us on the cell finalize -- the pole of every step in which the outermost
   // block still holds cells (tools/timeline.py mfe: +2.04 us against +1.27).  Small workgroups (emulation) keep it on a finalize wave.
-#ifndef DRNA_MFE_SWEEP_STAGE
-#define DRNA_MFE_SWEEP_STAGE 1
-#endif
-  const bool sweep_stage = DRNA_MFE_SWEEP_STAGE && !TWO_PAR && NBT >= 1;
+  const bool sweep_stage = !TWO_PAR && NBT >= 1;
   const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;

@@ -213,10 +213,7 @@ constexpr int KT_U = (2 * KT_NL + 3) / 4;           // near slots per row
 constexpr int KT_BMIN = (12 + 2 * PKE + 3) / 4;     // smallest block distance with a far range
 constexpr int KT_D0 = 4 * KT_BMIN - 3;              // first diagonal with a far split point
 constexpr int KT_MF = (4 * ((PF_FAST_NMAX - 1) / 4) - 11 - 2 * PKE + 15) / 16;   // products of the longest far range
-#ifndef DRNA_KT_DEPTH
-#define DRNA_KT_DEPTH 3
-#endif
-constexpr int KT_DEPTH = DRNA_KT_DEPTH;             // products of a tile in flight
+constexpr int KT_DEPTH = 3;                         // products of a tile in flight (3 / 5 / 11 measured: 0.551 / 0.553 / 0.563 ms at R = 128)
 static_assert(PKE >= 4, "a tile's operands must be final when the first of its four steps comes");
 
 // near split points of cell (i, i+d): nl from below, nh from above
@@ -261,10 +258,7 @@ __device__ __forceinline__ void k_near_row(RS rs, int tab8, int ld, int d, int i
 // by wave-uniform strides of 16 split points, which the buffer instructions take as a scalar offset; only the last product
 // clamps and masks), k_tile_finish multiplies, fetches what a long far range has beyond that KT_DEPTH products at a time, and
 // hands the sixteen sums to store(d, i, v).
-#ifndef DRNA_KT_PRE
-#define DRNA_KT_PRE 3
-#endif
-constexpr int KT_PRE = DRNA_KT_PRE < KT_MF - 1 ? DRNA_KT_PRE : KT_MF - 1;
+constexpr int KT_PRE = 3;                           // products k_tile_issue requests besides the last one
 struct KTile {
   double al, bl, av[KT_PRE], bv[KT_PRE];
   int vA, vB;                // a lane's operand addresses (product 0 of qm, the last but one of qm1)
@@ -564,18 +558,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     else if (aw < 4 * NBT) { my_tb = aw >> 2; const int x = (aw + my_tb) & 3; my_sig = x & 1; my_pm = 1 << (x >> 1); }
   }
   const int w_pl = NB > 2 ? 2 : 0, w_q5 = NB - 1;     // finalize waves that take the side jobs
-  // Option: the pairable-list row of the next diagonal staged into LDS by two SWEEP waves taking turns (block 0's even-size waves:
-  // the one whose towers rest in a step requests the row after next and writes it first thing in the following step, in which it
-  // is active), as fold_mfe_lds.hpp does it, where the staging sat on a finalize wave's cell finalize.  With a helper workgroup the late rows are the helper's: the first of them is requested at step
-  // PFL_D1 - 2, after the finalize waves have waited for the helper's flag of diagonal KT_D0 and a barrier has passed.
-  // -- measured and switched off here: the partition function's early steps are item-bound on exactly those waves (0.430 -> 0.438 ms
-  // at R = 64, 0.531 -> 0.542 at R = 128).
-#ifndef DRNA_PF_SWEEP_STAGE
-#define DRNA_PF_SWEEP_STAGE 0
-#endif
-  static_assert(PFL_D1 - 2 >= KT_D0, "a sweep wave reads a helper-built row only after the finalize waves have seen the helper's flag");
-  const bool sweep_stage = DRNA_PF_SWEEP_STAGE && !TWO_PAR && NBT >= 1 && !(DRNA_SKIP & 32);
-  const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
+  // (The list staging by two sweep waves taking turns, which fold_mfe_lds.hpp has, was measured here and dropped: this kernel's early
+  // steps are item-bound on exactly those waves -- 0.430 -> 0.438 ms at R = 64, 0.531 -> 0.542 at R = 128.)
 
   if (aw < 0) {
     const int d = TURN + 1;
@@ -749,7 +733,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
         pl0 = row[lane]; pl1 = row[lane + WAVE]; pl2 = row[lane + 2 * WAVE]; pl3 = row[min(lane + 3 * WAVE, ld - 1)];
       }
     };
-    if (!(DRNA_SKIP & 32) && !sweep_stage && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
+    if (!(DRNA_SKIP & 32) && wave == w_pl && TURN + 2 < n) pl_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       const int d = k - 1;
       TLMARK(0, k);
@@ -761,7 +745,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
       // come from beyond this XCD's L2, ~2 us, and with the request at the top of the SAME step the staging wave reached the
       // barrier last once the steps were down to the finalize chain): it goes into LDS here -- the items of this step read the
       // other parity's buffer -- and the row of diagonal k+2 is requested into the same registers.
-      if (!(DRNA_SKIP & 32) && !sweep_stage && wave == w_pl) {
+      if (!(DRNA_SKIP & 32) && wave == w_pl) {
         if (k + 1 < n) {
           int* dst = sm.plist[(k + 1) & 1];
           dst[lane] = pl0; dst[lane + WAVE] = pl1; dst[lane + 2 * WAVE] = pl2;
@@ -892,32 +876,8 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     double GE[TSL], GO[TSL];
 #pragma unroll
     for (int q = 0; q < TSL; q++) { GE[q] = 0.0; if (TWO_PAR) GO[q] = 0.0; }
-    int s_cnt = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;                  // the staged list row (stager waves)
-    auto st_request = [&](const int dn) {
-      const int32_t* row = PL + dn * ld;
-      if (hm && dn >= PFL_D1) {                                       // the helper's rows: sc1
-        s_cnt = ld_agent(row + ld - 1);
-        s0 = ld_agent(row + lane); s1 = ld_agent(row + lane + WAVE); s2 = ld_agent(row + lane + 2 * WAVE);
-        s3 = ld_agent(row + min(lane + 3 * WAVE, ld - 1));
-      } else {
-        s_cnt = row[ld - 1];
-        s0 = row[lane]; s1 = row[lane + WAVE]; s2 = row[lane + 2 * WAVE]; s3 = row[min(lane + 3 * WAVE, ld - 1)];
-      }
-    };
-    // (the wave that is active in the first step writes the second diagonal's row at its top: requested here)
-    if (stager && ((my_pm >> ((TURN + 1) & 1)) & 1) && TURN + 2 < n) st_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       TLMARK(0, k);
-      if (stager && k < n) {
-        if ((my_pm >> (k & 1)) & 1) {                                // active in this step: the row requested a step ago goes into LDS
-          if (k + 1 < n) {
-            int* dst = sm.plist[(k + 1) & 1];
-            dst[lane] = s0; dst[lane + WAVE] = s1; dst[lane + 2 * WAVE] = s2;
-            if (lane + 3 * WAVE < PfFastSmem<NT>::NL) dst[lane + 3 * WAVE] = s3;
-            if (lane == 0) { sm.pcnt[(k + 1) & 1] = s_cnt; sm.qhead[(k + 1) & 1] = 0; sm.qtile[(k + 1) & 1] = 0; }
-          }
-        } else if (k + 2 < n) st_request(k + 2);                     // resting: request the row after next
-      }
       if (k < n) {
         const int d = k;
         const int ncell = n - d, sh = d >> 1, par = d & 1;
