@@ -88,7 +88,8 @@ def test_eterna_v1_solutions(eng400, oracle, eterna_solutions):
             assert abs(float(out["Epf"][0]) - oracle.pf(r["sequence"])) < EPF_TOL_ORACLE, r["name"]     # all 100, up to 400 nt
 
 
-@pytest.mark.parametrize("L,R", [(1, 3), (4, 2), (5, 4), (8, 4), (63, 8), (64, 8), (65, 8), (100, 16), (129, 8)])
+@pytest.mark.parametrize("L,R", [(1, 3), (4, 2), (5, 4), (8, 4), (9, 4), (10, 4), (11, 4), (12, 4), (13, 4), (63, 8), (64, 8), (65, 8), (74, 8), (75, 8),
+                                 (100, 16), (129, 8), (138, 8), (139, 8)])      # (10 / 11, 74 / 75, 138 / 139: one tower block more)
 def test_random_vs_oracle(eng400, oracle, L, R):
     rng = np.random.default_rng(1000 + L)
     seqs = [_rand(rng, L) for _ in range(R - 1)] + [_rand(rng, L, "GC")]
