@@ -206,7 +206,7 @@ def test_kbest_structures_against_enumeration(emu, oracle):
                 assert x == "." * len(s)
 
 
-@pytest.mark.parametrize("L,nt,pk", [(24, 256, 0), (41, 256, 3)])
+@pytest.mark.parametrize("L,nt,pk", [(24, 256, 0), (41, 256, 3), (44, 1024, 0)])       # 1024 threads: the production roles (tower waves by size and diagonal parity, list staging by sweep waves, helper-built list rows)
 def test_two_workgroup_mfe_kernel(emu, oracle, L, nt, pk):
     """fold_mfe_dual.hpp on the CPU: the main and the helper workgroup of every sequence run side by side (OS threads), rows
     and flags go through ordinary memory; two calls in a row exercise the epoch arithmetic of the never-reset flags.
