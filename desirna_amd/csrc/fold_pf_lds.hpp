@@ -604,7 +604,11 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     const int nK = ((DRNA_SKIP & 8) || d < 2 * TURN + 3) ? 0 : nblk;
     const int nE = (DRNA_SKIP & 2) ? 0 : (pcnt + 3) >> 2, nX = (DRNA_SKIP & 4) ? 0 : 3 * ((pcnt + WAVE - 1) / WAVE);
     const int nItems = __builtin_amdgcn_readfirstlane(nK + nE + nX);
-    for (int it = queue_pop(&sm.qhead[par], lane); it < nItems; it = queue_pop(&sm.qhead[par], lane)) {
+    for (int it0 = queue_pop(&sm.qhead[par], lane); it0 < nItems; it0 = queue_pop(&sm.qhead[par], lane)) {
+      // The item index below is in the order K, E, X; the QUEUE hands them out as X, K, E: the items with global loads (tables of
+      // the 1x2 / 2x2 loops, multiloop operands) first, the bulge / 1xn items -- LDS only -- last, for the finalize waves, which join
+      // late and whose table stores a later global load would have to wait for (K, E, X: 0.428 ms; X, K, E: 0.417; K, X, E: 0.420; X, E, K: 0.457)
+      const int it = it0 < nX ? nK + nE + it0 : it0 - nX;
       if (it < nK) {
         // ---- K near: a lane owns two adjacent cells and fetches both operands of both with one 16-byte load each (the
         // vector-memory pipe, not the ALU, bounds this sweep: half the instructions, whole 128-byte lines per row)
