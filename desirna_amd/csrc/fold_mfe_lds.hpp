@@ -591,6 +591,10 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
   // block still holds cells (tools/timeline.py mfe: +2.04 us against +1.27).  Small workgroups (emulation) keep it on a finalize wave.
   const bool sweep_stage = !TWO_PAR && NBT >= 1;
   const bool stager = sweep_stage && my_tb == 0 && my_sig == 0;
+  // ... and the exterior column j = k - 3 by block 0's two odd-size waves, the one that rests in the step (its cells, diagonals
+  // <= k-4, were stored in step <= k-3): on a finalize wave the column was +0.5 us on the cell finalize of the last block
+  const bool sweep_q5 = sweep_stage;
+  const bool q5er = sweep_q5 && my_tb == 0 && my_sig == 1;
   // finalize waves that take the side jobs; wave 0 owns the outermost tower block, which has the fewest live cells
   const int w_tab = NB > 1 ? 1 : 0, w_pl = 0, w_q5 = NB - 1;
   // the shape table of the next diagonal goes to a wave of its own when there is one without a side job (n > 128: wave 2): with
@@ -761,7 +765,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         }
         if (k + 2 < n) pl_request(k + 2);
       }
-      if (wave == w_q5 && k - 3 >= TURN + 2) {
+      if (!sweep_q5 && wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
         const int nch = (j - TURN - 1 + WAVE - 1) >> 6;
 #pragma unroll
@@ -843,7 +847,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
         const int we = outer_idle ? NB - 1 : w_et;
         if (wave == we) mfe_prepare_etab(sm, k + 1, lane, DUAL ? E_NEAR : E_ALL);
       }
-      if (wave == w_q5 && k - 3 >= TURN + 2) {
+      if (!sweep_q5 && wave == w_q5 && k - 3 >= TURN + 2) {
         const int j = k - 3;
         int m = INF;
 #pragma unroll
@@ -910,6 +914,26 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     if (stager && ((my_pm >> ((TURN + 1) & 1)) & 1) && TURN + 2 < n) st_request(TURN + 2);
     for (int k = TURN + 1; k <= n; k++) {
       MTLMARK(0, k);
+      if (q5er && !((my_pm >> (k & 1)) & 1) && k - 3 >= TURN + 2) {
+        const int j = k - 3;
+        const int nch = (j - TURN - 1 + WAVE - 1) >> 6;
+        int fx[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int i = lane + 1 + c * WAVE;
+          fx[c] = INF;
+          if (c < nch && i <= j - TURN - 1) fx[c] = EXT[j * ld + i];
+        }
+        int m = INF;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int i = lane + 1 + c * WAVE;
+          if (i <= j - TURN - 1 && fx[c] < HALF) m = min(m, sm.f5[i - 1] + fx[c]);
+        }
+        m = wave_min_i32_lane63(m);        // DPP (no LDS traffic); lane 63 holds the minimum
+        const int prev = sm.f5[j - 1];
+        if (lane == WAVE - 1) sm.f5[j] = prev < m ? prev : m;
+      }
       if (stager && k < n) {
         if ((my_pm >> (k & 1)) & 1) {                              // active in this step: the row requested a step ago goes into LDS
           if (k + 1 < n) {
