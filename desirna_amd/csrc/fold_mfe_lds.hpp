@@ -13,6 +13,9 @@
 //    So each tower carries, IN REGISTERS, one running minimum per live inner diagonal d' (27 of them,
 //    spread over the waves pinned to the tower block) and a diagonal step costs 2 LDS reads per entry
 //    instead of enumerating all ~375 generic (u1,u2) candidates (the O(n^2 L) scheme of Lyngso et al.).
+//    (Since round 4 the entries of this kernel are indexed by the loop SIZE and a wave owns one parity of the size and one of the
+//    diagonal: mfe_tower2_step; the form indexed by the inner diagonal, mfe_tower_step with its per-diagonal table, serves
+//    the strip kernels, whose towers travel from strip to strip.)
 //    Stack, bulges, 1x1, 2x1, 1xn, 2x2 and 2x3 loops (121 candidates) are still enumerated from the
 //    host-built plan with wave-uniform size terms.
 //  * f5 is advanced one column per diagonal step by a spare wave, so no serial tail remains.
@@ -101,8 +104,8 @@ __device__ __forceinline__ void mfe_f5_column(MfeFastSmem<NT>& sm, const int32_t
   sm.f5[j] = prev < m ? prev : m;
 }
 
-// Per-diagonal table for diagonal d (written by a finalize wave one step ahead, so the sweep waves spend
-// no scalar instructions on offsets): residue rho of an inner diagonal -> ring offsets and size terms of
+// Per-diagonal table for diagonal d (strip kernels, fold_mfe_strip.hpp; written by a service wave one step ahead, so the tower
+// waves spend no scalar instructions on offsets): residue rho of an inner diagonal -> ring offsets and size terms of
 // the tower entry that lives there on diagonal d.
 template <class SM>
 __device__ __forceinline__ void mfe_prepare_etab(SM& sm, int d, int lane, int mode);
