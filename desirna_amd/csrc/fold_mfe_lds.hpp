@@ -1025,9 +1025,27 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
   }
 #endif
-  // the remaining exterior columns (every store has landed: the loop ended with a draining barrier)
-  if (wave == 0) {
-    for (int j = max(TURN + 2, n - 2); j <= n; j++) mfe_f5_column<NT>(sm, EXT, ld, j, lane);
+  // the remaining exterior columns (every store has landed: the loop ended with a draining barrier): their minima by one wave
+  // each, side by side (column j reads f5 up to j - 5, which the loop has left final), then the three-step recurrence by one lane
+  {
+    const int j0 = max(TURN + 2, n - 2);
+    if (NW >= 3) {
+      if (wave < 3 && j0 + wave <= n) {
+        const int j = j0 + wave;
+        int m = INF_DEV;
+        for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) {
+          const int x = EXT[j * ld + i];
+          if (x < INF_DEV / 2) m = min(m, sm.f5[i - 1] + x);
+        }
+        m = wave_min_i32(m);
+        if (lane == 0) sm.tbq[wave] = m;                 // (the traceback's queue words: not in use yet)
+      }
+      __syncthreads();
+      if (tid == 0)
+        for (int j = j0; j <= n; j++) { const int prev = sm.f5[j - 1], m = sm.tbq[j - j0]; sm.f5[j] = prev < m ? prev : m; }
+    } else if (wave == 0) {
+      for (int j = j0; j <= n; j++) mfe_f5_column<NT>(sm, EXT, ld, j, lane);
+    }
   }
   __syncthreads();
 }

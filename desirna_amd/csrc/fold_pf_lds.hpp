@@ -924,9 +924,25 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
     for (int k = 0; k < 8; k++) dbg[wave * 8 + k] = st_acc[k];
 #endif
   TLMARK(0, 2);
-  // the remaining exterior columns, then Z
+  // the remaining exterior columns -- their sums by one wave each, side by side (column j reads q5 up to j - 5, which the loop has
+  // left final; the same lanes add the same terms in the same order as pf_q5_column), the three-step recurrence by one lane -- then Z
+  const int jq0 = max(TURN + 2, n - 2);
+  if (NW >= 3) {
+    if (wave < 3 && jq0 + wave <= n) {
+      const int j = jq0 + wave;
+      double sq = 0.0;
+      for (int i = lane + 1; i <= j - TURN - 1; i += WAVE) sq += sm.q5[i - 1] * QEXT[j * ld + i];
+      sq = wave_total_f64_lane63(sq);
+      if (lane == WAVE - 1) sm.xc[13 + wave] = sq;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int j = jq0; j <= n; j++) sm.q5[j] = sm.q5[j - 1] * sc1 + sm.xc[13 + j - jq0];
+    __syncthreads();
+  } else if (wave == 0) {
+    for (int j = jq0; j <= n; j++) pf_q5_column<NT>(sm, QEXT, ld, j, lane, sc1);
+  }
   if (wave == 0) {
-    for (int j = max(TURN + 2, n - 2); j <= n; j++) pf_q5_column<NT>(sm, QEXT, ld, j, lane, sc1);
     if (lane == 0) {
       const double Z = sm.q5[n];
       if (!(Z > 0.0) || !(Z < 1.0e300)) {
