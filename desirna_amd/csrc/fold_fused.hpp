@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NT) void score_fused_kernel(MfeArgs MA, DualLink lk
     if (role == ROLE_MFE_HELPER) mfe_helper<NT>(*reinterpret_cast<MfeHelperSmem<NT>*>(raw), MA, r, lk);
     else mfe_lds_body<NT, true>(*reinterpret_cast<MfeFastSmem<NT>*>(raw), MA, r, lk);
   } else {
-    pf_lds_body<NT>(*reinterpret_cast<PfFastSmem<NT>*>(raw), PA, EV, r, role == ROLE_PF_HELPER ? 1 : 0);
+    pf_lds_body<NT, false>(*reinterpret_cast<PfFastSmem<NT>*>(raw), PA, EV, r, role == ROLE_PF_HELPER ? 1 : 0);      // (the fused launch always has helper workgroups: the instance without tile code)
   }
   if (clk && threadIdx.x == 0) clk[2 * blockIdx.x + 1] = wall_clock_100mhz();
 }
