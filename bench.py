@@ -160,7 +160,7 @@ def roofline_block(dom, dom_ms, L, R, tk, fused=False):
     tools/gpu_round4.sh); kernel time is measured live here, and a live time more than 5 % away from the profiled run's is flagged."""
     src = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     mfe_b, pf_b = b_alg_bytes(L)
-    stream = (pf_b if dom == "pf" else mfe_b) * R
+    stream = (pf_b + mfe_b if fused else pf_b if dom == "pf" else mfe_b) * R        # (one launch: both folds' operands)
     out = {"bound": None, "kernel": ("%s_lds_kernel<1024>" if L <= 200 else "%s_kernel<1024>") % dom, "achieved": None,
            "peak": None, "unit": None, "frac": None, "traffic": None,
            "operand_stream": {"bytes_per_launch": stream, "GB_per_s": stream / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
@@ -558,7 +558,8 @@ def main():
                        "threads_per_workgroup": eng.info()["threads_per_wg"],
                        "launches_per_step": 1 if fused else 2},
             "kernel_ms": {k: round(v, 4) for k, v in tk.items()},
-            "roofline": roofline_block(dom, tk[dom], L, R, tk, fused),
+            # (one launch for both folds: the kernel whose counters the inputs hold is that launch, its duration the step's device time)
+            "roofline": roofline_block(dom, tk["total"] if fused else tk[dom], L, R, tk, fused),
         }
         rb = out["roofline"]
         hb = rb.get("step_hbm")

@@ -115,8 +115,9 @@ struct drna_engine {
                                   // partition function (fold_pf_lds.hpp, pf_kfar_helper); option "pf_helper"
   int* d_pflags = nullptr;        // its hand-over flags: per sequence two 128-byte lines
   int pflags_cap = 0, pfh_epoch = 0;
-  bool fused = false;             // small batches: both folds in ONE launch of 4 R workgroups (fold_fused.hpp); option "fused", DRNA_FUSED=1.
-                                  // Off by default: within 1 % of the two launches either way (the host pays the same 14 us)
+  bool fused = true;              // small batches: both folds in ONE launch of 4 R workgroups (fold_fused.hpp); option "fused", DRNA_FUSED=0 turns it off.
+                                  // On since the end of round 4: 0.413 against 0.420 ms of device time at R = 64 x L = 200 (the two launches' kernels
+                                  // start and end a few us apart; the host pays the same 14 us either way)
   int fused_blocks_per_cu = -1;   // occupancy query of the fused kernel (-1: not asked yet)
   int pair_blocks_per_cu = -1;    // ... of the two-workgroup MFE kernel and the partition function with helpers (the smaller of the two answers)
   long long *h_clk = nullptr, *d_clk = nullptr;   // host-mapped: start / end wall clock of every block of the fused launch

@@ -969,9 +969,9 @@ def test_bench_line_carries_parity_roofline_baseline_and_the_monte_carlo_loop():
 
 
 def test_one_launch_form_equals_the_two_launches(eng400, oracle, eterna_targets):
-    """Option "fused": both folds of a small batch in ONE launch of 4 R workgroups (fold_fused.hpp; off by default: measured
-    0.5 % slower).  Same device functions, so every output is bit for bit that of the two launches; odd batch sizes leave idle
-    blocks at the end of the grid; pseudoknot rounds run inside the MFE roles."""
+    """Option "fused" (the default): both folds of a small batch in ONE launch of 4 R workgroups (fold_fused.hpp).  Same device
+    functions, so every output is bit for bit that of the two launches; odd batch sizes leave idle blocks at the end of the grid;
+    pseudoknot rounds run inside the MFE roles."""
     from desirna_amd import engine as E
     rng = np.random.default_rng(4141)
     tg = eterna_targets["eteV1_69.txt"]
@@ -980,15 +980,18 @@ def test_one_launch_form_equals_the_two_launches(eng400, oracle, eterna_targets)
         seqs = [_rand(rng, L) for _ in range(R)]
         eng400.set_targets([t])
         flags = E.NEED_PF | E.NEED_MFE | E.NEED_EVAL | (E.NEED_PK if pk else 0)
-        a = eng400.score_batch(seqs, flags)
-        assert eng400.get_option("last_fused") == 0
-        eng400.set_option("fused", 1)
+        default = eng400.get_option("fused")
+        assert default == 1
         try:
+            eng400.set_option("fused", 0)
+            a = eng400.score_batch(seqs, flags)
+            assert eng400.get_option("last_fused") == 0
+            eng400.set_option("fused", 1)
             b = eng400.score_batch(seqs, flags)
             assert eng400.get_option("last_fused") == 1 and eng400.get_option("last_workgroups") == 4 * R
             c = eng400.score_batch(seqs, flags)
         finally:
-            eng400.set_option("fused", 0)
+            eng400.set_option("fused", default)
         for x in (b, c):
             assert x["mfe_ss"] == a["mfe_ss"] and (x["Emfe"] == a["Emfe"]).all() and (x["Ed"] == a["Ed"]).all()
             assert (x["Epf"].view(np.int64) == a["Epf"].view(np.int64)).all()

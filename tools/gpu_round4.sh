@@ -18,12 +18,13 @@ if has bench; then
   cat $O/bench_uniform.json
   timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --seqs design --no-cpu-baseline --no-r-sweep > $O/bench_design.json 2>/dev/null || exit 1
   DRNA_PF_HELPER=0 timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-r-sweep > $O/bench_nohelper.json 2>/dev/null || exit 1
+  DRNA_FUSED=0 timeout -k 10 200 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-r-sweep > $O/bench_two_launches.json 2>/dev/null || exit 1
   DRNA_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_gloo2_rehearsal.json 2> $O/bench_gloo2.err || { tail -5 $O/bench_gloo2.err; }
   DRNA_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --scaling strong --steps 20 --warmup 3 > $O/bench_gloo2_strong_rehearsal.json 2> $O/bench_gloo2_strong.err || { tail -5 $O/bench_gloo2_strong.err; }
   timeout -k 10 300 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-mc-loop --r-sweep > $O/bench_rsweep.json 2>/dev/null || exit 1
   python3 -c "
 import json
-for f in ('bench_uniform','bench_design','bench_nohelper','bench_gloo2_rehearsal','bench_gloo2_strong_rehearsal','bench_rsweep'):
+for f in ('bench_uniform','bench_design','bench_nohelper','bench_two_launches','bench_gloo2_rehearsal','bench_gloo2_strong_rehearsal','bench_rsweep'):
     try:
         d=json.load(open('$O/'+f+'.json')); print('%-24s value %.0f n_gpus %d ms/step %.4f kernel_ms %s' % (f, d['value'], d['n_gpus'], d['ms_per_step'], d['kernel_ms']))
     except Exception as ex: print(f, 'FAILED', ex)
@@ -40,6 +41,9 @@ if has pmc; then
     name=$1; shift
     rm -rf gpurun_out/pmc_$name
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/pmc_$name" -o $name -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-mc-loop --no-r-sweep > /dev/null 2> "$REPO/gpurun_out/pmc_$name.err") || { tail -3 gpurun_out/pmc_$name.err; return 1; }
+    # the two-launch form (DRNA_FUSED=0) as well: its kernels' inputs stay in the file beside the one-launch kernel's
+    rm -rf gpurun_out/pmc2_$name
+    (cd /tmp && DRNA_FUSED=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/pmc2_$name" -o $name -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-mc-loop --no-r-sweep > /dev/null 2> "$REPO/gpurun_out/pmc2_$name.err") || { tail -3 gpurun_out/pmc2_$name.err; return 1; }
     rm -rf gpurun_out/cal_$name
     (cd /tmp && timeout -k 10 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/gpurun_out/cal_$name" -o $name -- "$REPO/tools/pmc_calib" > /dev/null 2> "$REPO/gpurun_out/cal_$name.err") || { tail -3 gpurun_out/cal_$name.err; return 1; }
   }

@@ -26,7 +26,7 @@ def key_of(kname):
 def grid_workgroups():
     """workgroups per launch of every kernel, from the kernel trace of a PMC pass"""
     out = {}
-    for f in glob.glob(os.path.join(G, "pmc_sq1", "**", "*kernel_trace.csv"), recursive=True):
+    for f in glob.glob(os.path.join(G, "pmc_sq1", "**", "*kernel_trace.csv"), recursive=True) + glob.glob(os.path.join(G, "pmc2_sq1", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             try:
                 out[r["Kernel_Name"]] = float(r["Grid_Size_X"]) / float(r["Workgroup_Size_X"])
@@ -37,8 +37,9 @@ def grid_workgroups():
 
 raw, cal = {}, {}
 for p in ("fetch", "write", "sq1", "sq2", "grbm"):
-    for k, d in counters("pmc", p).items():
-        raw.setdefault(k, {}).update(d)
+    for pre in ("pmc", "pmc2"):                      # pmc2: the same passes with DRNA_FUSED=0 (the two-launch form's kernels)
+        for k, d in counters(pre, p).items():
+            raw.setdefault(k, {}).update(d)
     for k, d in counters("cal", p).items():
         cal.setdefault(k, {}).update(d)
 if not raw:
@@ -100,8 +101,9 @@ for k, d in raw.items():
     if "GRBM_GUI_ACTIVE" in d and key in stats:
         e["clock_hz_grbm"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (stats[key]["avg_ns"] * 1e-9)
     if 15 in floor:
-        e["floor_ms"] = floor[15][key] if key in floor[15] else None
-        e["full_ms_same_run"] = floor.get(0, {}).get(key)
+        # the one-launch kernel holds both folds: its floor is the longer of the two roles'
+        e["floor_ms"] = floor[15][key] if key in floor[15] else max(floor[15].values()) if key == "fused" else None
+        e["full_ms_same_run"] = floor.get(0, {}).get(key) if key != "fused" else (max(floor[0].values()) if 0 in floor else None)
         e["floor_build"] = "-DDRNA_SKIP=15 of the production launch configuration (tools/phase_cost.py): %s" % k
     if key in stats:
         e["rocprof_avg_ms"] = stats[key]["avg_ns"] * 1e-6
