@@ -703,7 +703,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     bool first = true;
     for (int b = 0; b < grid; b++) {
       int r, role;
-      fused_block_role(b, r, role);
+      fused_block_role(b, r, role, grid);
       if (r >= R) continue;
       const long long s0 = e->h_clk[2 * b], s1 = e->h_clk[2 * b + 1];
       if (first || s0 < t0) t0 = s0;

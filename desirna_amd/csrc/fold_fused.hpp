@@ -9,10 +9,12 @@
 // instead of two.  Results are those of the separate kernels, bit for bit (the same device functions run).
 //
 // Block -> (sequence, role).  Blocks are dealt round-robin over the 8 XCDs (block b on XCD b % 8: speed only, never relied on
-// for correctness), each with its own L2.  With q = b >> 3 and x = b & 7: sequence r = 2 q + (x >> 2), role = (x + FUSED_ROT q) & 3
-// (0 MFE main, 1 MFE helper, 2 PF main, 3 PF helper): the four roles of a sequence sit on four different XCDs.  FUSED_ROT = 2
-// keeps what the two separate launches had -- main roles on the even XCDs, helpers on the odd ones, both folds' main roles mixed
-// evenly over their XCDs; 1 mixes all four roles over all XCDs; 0 pins every role to two XCDs.
+// for correctness), each with its own L2.  The grid is four runs of rp = R rounded up to a multiple of 8 blocks, one run per role
+// -- MFE main, PF main, MFE helper, PF helper -- and block k rp + r is sequence r: the four workgroups of a sequence sit on the
+// SAME XCD (rp is a multiple of 8), so what they hand each other (rows, list rows, flags: agent-scope stores and loads) meets in
+// that XCD's L2, and every XCD holds the same number of workgroups of each role.  Measured against round 4's first mapping (the
+// four roles of a sequence on four XCDs, main roles on the even ones): the launch 0.4105 -> 0.4048 ms; the order of the runs does
+// not matter (helpers first: 0.4049), interleaving the two main roles' runs loses half of it (0.4078).
 #pragma once
 #include "fold_mfe_dual.hpp"
 #include "fold_pf_lds.hpp"
@@ -20,15 +22,12 @@
 namespace drna {
 
 enum : int { ROLE_MFE_MAIN = 0, ROLE_MFE_HELPER = 1, ROLE_PF_MAIN = 2, ROLE_PF_HELPER = 3 };
-#ifndef DRNA_FUSED_ROT
-#define DRNA_FUSED_ROT 2
-#endif
-__host__ __device__ inline void fused_block_role(int b, int& r, int& role) {
-  const int q = b >> 3, x = b & 7;
-  r = 2 * q + (x >> 2);
-  role = (x + DRNA_FUSED_ROT * q) & 3;
+__host__ __device__ inline int fused_grid(int R) { return 4 * ((R + 7) / 8 * 8); }
+__host__ __device__ inline void fused_block_role(int b, int& r, int& role, int grid) {
+  const int rp = grid >> 2, k = b / rp;
+  r = b - k * rp;
+  role = k == 0 ? ROLE_MFE_MAIN : k == 1 ? ROLE_PF_MAIN : k == 2 ? ROLE_MFE_HELPER : ROLE_PF_HELPER;
 }
-__host__ __device__ inline int fused_grid(int R) { return 8 * ((R + 1) / 2); }
 
 // clk (optional, host-mapped): per block the 100 MHz wall clock at its start and end, from which the host reads the time of
 // each fold without a profiler (the HIP events around the launch only see the whole kernel)
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(NT) void score_fused_kernel(MfeArgs MA, DualLink lk
   constexpr size_t BYTES = B0 > sizeof(PfFastSmem<NT>) ? B0 : sizeof(PfFastSmem<NT>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
   int r, role;
-  fused_block_role(blockIdx.x, r, role);
+  fused_block_role(blockIdx.x, r, role, gridDim.x);
   if (r >= R) return;
   if (clk && threadIdx.x == 0) clk[2 * blockIdx.x] = wall_clock_100mhz();
   if (role == ROLE_MFE_MAIN || role == ROLE_MFE_HELPER) {
