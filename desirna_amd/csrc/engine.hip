@@ -620,9 +620,9 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->last_wgs += pf_strips ? R * pf_strips : pf_help ? 2 * R : R;
     if (pf_strips) launch_pf_strips(e, a, R, pf_strips, 0, nullptr, e->s_pf);
     else if (pf_help)
-      hipLaunchKernelGGL((pf_lds_kernel<1024, false>), dim3(2 * R), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{});
+      hipLaunchKernelGGL((pf_lds_kernel<1024, false>), dim3(pair_grid(R)), dim3(1024), 0, e->s_pf, a, ev_in_pf ? make_eval_args() : EvalArgs{}, R);
     else if (e->lds_path && e->nt == 1024 && L <= PF_FAST_NMAX)
-      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{});
+      hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(R), dim3(1024), 0, e->s_pf, a, EvalArgs{}, R);
     else if (e->nt == 256) launch_pf<256>(a, R, e->s_pf);
     else if (e->nt == 512) launch_pf<512>(a, R, e->s_pf);
     else launch_pf<1024>(a, R, e->s_pf);
@@ -650,7 +650,7 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
     e->last_wgs += use_dual ? 2 * R : mfe_strips ? R * mfe_strips : R;
     if (use_dual) {
       DualLink lk = make_dual_link();
-      hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(2 * R), dim3(1024), 0, e->s_mfe, a, lk);
+      hipLaunchKernelGGL(mfe_dual_kernel<1024>, dim3(pair_grid(R)), dim3(1024), 0, e->s_mfe, a, lk, R);
     } else if (mfe_strips && a.pk_rounds > 0 && R >= 16 * e->mfe_split && e->mfe_split > 1) {
       // every round is a fill launch and a traceback launch (one wave per sequence, ~0.2 ms with the chip idle): the batch goes
       // in parts on two streams, so that one part's traceback runs under another part's fill
@@ -1188,7 +1188,7 @@ extern "C" int drna_score_ragged(drna_engine* e, int R, const int32_t* lens, con
       part(idxA, nA, c0, c1, f, m);
       if (m) {
         a.rg.idx = e->d_rg + (size_t)3 * R + f;
-        hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(m), dim3(1024), 0, e->s_pf, a, EvalArgs{});
+        hipLaunchKernelGGL(pf_lds_kernel<1024>, dim3(m), dim3(1024), 0, e->s_pf, a, EvalArgs{}, m);
       }
     }
     HIP_TRY(hipGetLastError());

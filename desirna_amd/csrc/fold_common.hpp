@@ -239,6 +239,17 @@ constexpr int STRIP_MAXS = 18;                         // strips per sequence at
 constexpr int STRIP_WMAX = 120;                       // widest strip of the production kernel (1024 threads)
 constexpr int STRIP_NMAX = STRIP_MAXS * STRIP_WMAX;   // longest sequence
 
+// Two workgroups per sequence in one launch (mfe_dual_kernel, pf_lds_kernel with helpers): blocks in groups of 16 -- eight main
+// roles, then their eight helpers -- so that a sequence's two workgroups are 8 blocks apart, i.e. on ONE XCD when blocks are dealt
+// round-robin over the 8 XCDs (speed only, never relied on): what they hand each other meets in that XCD's L2 (fold_fused.hpp has
+// the measurement).  Blocks whose sequence is beyond the batch leave at once.
+__host__ __device__ inline int pair_grid(int R) { return 16 * ((R + 7) / 8); }
+__host__ __device__ inline void pair_block(int b, int& r, int& helper) {
+  const int x = b & 15;
+  r = (b >> 4) * 8 + (x & 7);
+  helper = x >> 3;
+}
+
 struct StripLink {
   int* flags = nullptr;      // one 128-byte line per (sequence slot, strip)
   int base = 0;              // epoch << 12

@@ -2,7 +2,7 @@
 // enough that half of the chip would otherwise idle (R = 64 replicas: 2 folds x 64 workgroups on 256 CUs).  Same recursions
 // and results, bit for bit, as mfe_lds_kernel (reference utils/energy_scores.py:151).
 //
-// Roles (workgroups 2r and 2r+1 of the grid fold sequence r):
+// Roles (two workgroups of the grid fold sequence r, 8 blocks apart = on one XCD: pair_block, fold_common.hpp):
 //   MAIN   (mfe_lds_body<NT, true>, fold_mfe_lds.hpp): finalize, tower step (generic interior loops), the six NEAR shapes
 //          whose inner pair is at most four diagonals back, exterior column, traceback, pseudoknot rounds.  After every
 //          diagonal it publishes the ring word and the fML value of each cell.
@@ -222,18 +222,21 @@ __device__ __forceinline__ void mfe_helper(MfeHelperSmem<NT>& sm, MfeArgs A, int
   }
 }
 
-// grid = 2 R workgroups: 2r = main, 2r+1 = helper of sequence r.  LDS is one buffer used as either role's struct.
+// grid = pair_grid(R) workgroups: main and helper of a sequence 8 blocks apart (pair_block, fold_common.hpp).  LDS is one buffer
+// used as either role's struct.
 template <int NT>
-__global__ __launch_bounds__(NT) void mfe_dual_kernel(MfeArgs A, DualLink lk) {
+__global__ __launch_bounds__(NT) void mfe_dual_kernel(MfeArgs A, DualLink lk, int R) {
   constexpr size_t BYTES = sizeof(MfeFastSmem<NT>) > sizeof(MfeHelperSmem<NT>) ? sizeof(MfeFastSmem<NT>) : sizeof(MfeHelperSmem<NT>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
-  const int r = blockIdx.x >> 1;
+  int r, is_helper;
+  pair_block(blockIdx.x, r, is_helper);
+  if (r >= R) return;
   // per-sequence slices of the link
   lk.flagA += r * 64; lk.flagB += r * 64 + 32;
   lk.xs += (long long)r * 256;
   lk.xa = reinterpret_cast<int32_t*>(lk.xa) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
   lk.xb = reinterpret_cast<int32_t*>(lk.xb) + (long long)r * 2 * (MFE_FAST_NMAX + 2) * XP;
-  if (blockIdx.x & 1) mfe_helper<NT>(*reinterpret_cast<MfeHelperSmem<NT>*>(raw), A, r, lk);
+  if (is_helper) mfe_helper<NT>(*reinterpret_cast<MfeHelperSmem<NT>*>(raw), A, r, lk);
   else mfe_lds_body<NT, true>(*reinterpret_cast<MfeFastSmem<NT>*>(raw), A, r, lk);
 }
 

@@ -607,7 +607,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
 
 #ifdef DRNA_TL
   long long* ptl2 = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
-  const bool ptl2_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0 && tid == 0;
+  const bool ptl2_on = Wc == A.ws && tid == 0;            // (sequence 0's main workgroup, whatever the block mapping)
 #define PTL2(x) do { if (ptl2_on) ptl2[256 + (x)] = (long long)wall_clock64(); } while (0)
 #else
 #define PTL2(x) do { } while (0)
@@ -700,7 +700,7 @@ __device__ __forceinline__ void mfe_fill_lds(MfeFastSmem<NT>& sm, const MfeArgs&
 #endif
 #ifdef DRNA_TL
   long long* mtl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
-  const bool mtl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0;
+  const bool mtl_on = Wc == A.ws;
 #endif
   if (aw < 0) {
     // ================= finalize waves
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void mfe_lds_body(MfeFastSmem<NT>& sm, MfeArgs A, int
   // phase marks of sequence 0's (main) workgroup (tools/timeline.py mfe): kernel entry, fill done, traceback done (steps start at
   // TURN + 1: slots 0 .. 3 of every event row are free); PTL2 in mfe_fill_lds: the parts of the first round's prologue
   long long* ptl = reinterpret_cast<long long*>(Wc + 2ll * ld * ld);
-  const bool ptl_on = (DUAL ? blockIdx.x >> 1 : blockIdx.x) == 0 && tid == 0;
+  const bool ptl_on = Wc == A.ws && tid == 0;
   if (ptl_on) { ptl[0] = (long long)wall_clock64(); ptl[12287] = 0; }
 #endif
   for (int k = tid; k < 64; k += NT) sm.stack[k] = T.stack[k];

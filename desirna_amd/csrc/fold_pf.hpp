@@ -31,7 +31,7 @@ struct PfArgs {
   double* q5out = nullptr;     // optional: q5[0..L] per sequence for the outside recursion (fold_outside.hpp)
   long long q5_stride = 0;     // doubles per sequence
   Ragged rg;                   // ragged batch: per-sequence length / offsets (L is then overwritten per workgroup)
-  // pf_lds_kernel with a helper workgroup per sequence (fold_pf_lds.hpp, pf_kfar_helper): grid 2 R, block 2r = main, 2r+1 = helper
+  // pf_lds_kernel with a helper workgroup per sequence (fold_pf_lds.hpp, pf_kfar_helper): grid pair_grid(R), blocks by pair_block (fold_common.hpp)
   int* hflags = nullptr;       // per sequence two 128-byte lines: [r * 64] written by the main workgroup, [r * 64 + 32] by the helper
   int hbase = 0;               // epoch << 12; flag = hbase + last published diagonal (compares are wrap-safe)
   int helper = 0;

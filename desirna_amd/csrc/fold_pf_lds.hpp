@@ -455,7 +455,7 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
   constexpr int NW = NT / WAVE;
   constexpr int RS = PfFastSmem<NT>::RS;
   const PfTables& T = *A.T;
-  const bool hm = A.helper != 0;                     // a helper workgroup (odd blocks) computes the far multiloop split points
+  const bool hm = A.helper != 0;                     // a helper workgroup per sequence computes the far multiloop split points (emulator: odd blocks; kernel: pair_block)
   const int bx = bx_in >= 0 ? bx_in : hm ? blockIdx.x >> 1 : blockIdx.x;
   const bool is_helper = hm && (helper_in >= 0 ? helper_in != 0 : (blockIdx.x & 1) != 0);
   const int r = A.rg.idx ? A.rg.idx[bx] : bx;
@@ -959,10 +959,15 @@ __device__ __forceinline__ void pf_lds_body(PfFastSmem<NT>& sm, PfArgs A, const 
 }
 
 template <int NT, bool TILES = true>
-__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A, EvalArgs EV) {      // EV.n_targets > 0 (helper launches only): E(targets) too
+__global__ __launch_bounds__(NT) void pf_lds_kernel(PfArgs A, EvalArgs EV, int R) {      // EV.n_targets > 0 (helper launches only): E(targets) too
   __shared__ PfFastSmem<NT> sm;
   if (!TILES && !A.helper) return;               // (the engine launches this instance with helper workgroups only)
-  pf_lds_body<NT, TILES>(sm, A, EV);
+  int bx = -1, is_helper = -1;                   // (no helpers: grid = R or the index list's length, block = sequence)
+  if (A.helper) {                                // grid = pair_grid(R): main and helper of a sequence 8 blocks apart (pair_block)
+    pair_block(blockIdx.x, bx, is_helper);
+    if (bx >= R) return;
+  }
+  pf_lds_body<NT, TILES>(sm, A, EV, bx, is_helper);
 }
 
 }  // namespace drna

@@ -207,8 +207,8 @@ int emu_pf(const int32_t* blob, int n_int32, int R, int L, const char* seqs, int
       if (nt == 64) pf_kernel<64>(a);
       else if (nt == 128) pf_kernel<128>(a);
       else if (nt == 256) pf_kernel<256>(a);
-      else if (nt == -256 || nt == -257) pf_lds_kernel<256>(a, EvalArgs{});
-      else pf_lds_kernel<1024>(a, EvalArgs{});
+      else if (nt == -256 || nt == -257) pf_lds_kernel<256>(a, EvalArgs{}, 0);
+      else pf_lds_kernel<1024>(a, EvalArgs{}, 0);
     };
     if (helper) {           // two workgroups side by side, each with an LDS image of its own
       auto* s256 = new PfFastSmem<256>[2];
@@ -299,7 +299,7 @@ int emu_ragged(const int32_t* blob, int n_int32, int R, int max_L, const int32_t
     b.rg.len = lens; b.rg.off = offs;
     if (lds) {
       emu_launch(r, 256, [&]() { mfe_lds_kernel<256>(a); });
-      emu_launch(r, 256, [&]() { pf_lds_kernel<256>(b, EvalArgs{}); });
+      emu_launch(r, 256, [&]() { pf_lds_kernel<256>(b, EvalArgs{}, 0); });
     } else {
       emu_launch(r, 128, [&]() { mfe_kernel<128>(a); });
       emu_launch(r, 128, [&]() { pf_kernel<128>(b); });
