@@ -528,10 +528,12 @@ extern "C" int drna_score_batch_device(drna_engine* e, int R, int L, const char*
   // pay).  Needs 4 R <= CUs; larger batches keep the one-workgroup kernels, which saturate the chip by themselves
   // (R = 64 x L = 200: the MFE fold takes 0.50 instead of 0.59 ms, 1.65 instead of 1.81 ms with the pseudoknot re-folds; the
   // partition function running beside it loses 1 % to the busier chip's lower clock)
-  // Shorter sequences do not repay the hand-shake (measured break-even at n = 160: tools/dual_lengths.py).
+  // Shorter sequences do not repay the hand-shake: break-even (tools/dual_lengths.py, R = 64, with a sequence's two workgroups on
+  // one XCD) at n = 120 without pseudoknot rounds (n = 130: 0.275 against 0.292 ms, n = 160: 0.336 against 0.383) and at n = 165
+  // with them (their re-folds of masked sequences have little for the helper to do).
   const long long resident = (long long)e->cus * ((e->dual || e->pf_helper) && e->nt == 1024 ? pair_blocks_per_cu(e) : 1);   // workgroups the chip holds at once
   const bool use_dual = e->dual && e->lds_path && e->nt == 1024 && L <= MFE_FAST_NMAX && L > 2 * TURN + 2 && 4ll * R <= resident &&
-                        (L >= 170 || e->dual_force);
+                        (L >= (want_pk ? 170 : 125) || e->dual_force);
   if (use_dual) {
     if (e->dual_cap < R) {
       void* old[] = {e->d_dflags, e->d_xs, e->d_xa_mfe, e->d_xb_mfe};

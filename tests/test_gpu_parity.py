@@ -975,7 +975,7 @@ def test_one_launch_form_equals_the_two_launches(eng400, oracle, eterna_targets)
     from desirna_amd import engine as E
     rng = np.random.default_rng(4141)
     tg = eterna_targets["eteV1_69.txt"]
-    for L, R, pk in ((200, 64, False), (200, 63, True), (180, 5, False)):
+    for L, R, pk in ((200, 64, False), (200, 63, True), (180, 5, False), (130, 9, False)):      # (two workgroups per MFE fold from 125 nt on, 170 with pk rounds)
         t = tg[:L] if L == 200 else "." * L
         seqs = [_rand(rng, L) for _ in range(R)]
         eng400.set_targets([t])
