@@ -163,7 +163,11 @@ static size_t mfe_ws_stride(int ld) { return (size_t)5 * ld * ld; }             
 // hand-over flags hold (epoch << 12 | diagonal) for the strips and ((epoch * 8 + round) << 10 | diagonal) for the two-workgroup
 // kernel, compared wrap-safe: valid while live values are less than 2^31 apart, i.e. 2^19 (2^18) epochs.  Reset at a quarter of that.
 constexpr int STRIP_EPOCH_RESET = 1 << 17, DUAL_EPOCH_RESET = 1 << 16;
-constexpr int PF_HELPER_NMIN = 120;       // shorter sequences have too few far split points to repay a second workgroup
+#ifndef DRNA_PF_HELPER_NMIN
+#define DRNA_PF_HELPER_NMIN 95
+#endif
+constexpr int PF_HELPER_NMIN = DRNA_PF_HELPER_NMIN;       // shorter sequences have too few far split points to repay a second workgroup
+                                                          // (tools/pf_helper_lengths.py, R = 64: 90 nt 0.159 against 0.161 ms, 100 nt 0.176 against 0.182, 120 nt 0.215 against 0.228)
 
 // strips of a sequence of length n (0 = not a strip case): widest strip STRIP_WMAX columns; the exchange records of the
 // S - 1 strip boundaries must fit tables 0 and 1 of the sequence's workspace

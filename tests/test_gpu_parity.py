@@ -833,18 +833,18 @@ def test_lost_pf_helper_costs_milliseconds(eng400, oracle):
 def test_tile_products_give_the_same_bits_whoever_computes_them(eng400, oracle):
     """The far multiloop split points of the partition function are 4 x 4 tile products (fold_pf_lds.hpp): computed by
     the helper workgroup in small batches, by the main workgroup's sweep waves otherwise -- same device functions, so Epf must
-    agree BITWISE between the two (the engine gives a fold a helper from 120 nt on; the emulated kernels compare the two at 30, 64
+    agree BITWISE between the two (the engine gives a fold a helper from 95 nt on; the emulated kernels compare the two at 30, 64
     and 96 nt), at lengths that leave ragged tiles; and with the oracle to 1e-9, also where a single block distance has a far
     range (21 .. 24 nt: the first tiles) or none at all."""
     from desirna_amd import engine as E
     rng = np.random.default_rng(4242)
     try:
-        for L in (20, 21, 22, 23, 24, 37, 64, 97, 120, 121, 122, 123, 131, 150, 177, 199, 200):
+        for L in (20, 21, 22, 23, 24, 37, 64, 94, 95, 97, 120, 121, 122, 123, 131, 150, 177, 199, 200):
             seqs = [_rand(rng, L) for _ in range(4)] + ["GC" * (L // 2) + "A" * (L % 2)]
             eng400.set_targets(["." * L])
             eng400.set_option("pf_helper", 1)
             a = eng400.score_batch(seqs, E.NEED_PF)
-            assert eng400.get_option("last_workgroups") == (2 if L >= 120 else 1) * len(seqs), L       # main + helper per fold from 120 nt on
+            assert eng400.get_option("last_workgroups") == (2 if L >= 95 else 1) * len(seqs), L       # main + helper per fold from 95 nt on
             eng400.set_option("pf_helper", 0)
             b = eng400.score_batch(seqs, E.NEED_PF)
             assert eng400.get_option("last_workgroups") == len(seqs), L
